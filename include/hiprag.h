@@ -1,0 +1,134 @@
+/*
+ * hiprag.h -- C-ABI of libhiprag.so, the MI355X (gfx950) hybrid-retrieval hot path.
+ *
+ * This is the drop-in boundary for batd-htplus/intool-rag's retrieval path.  The reference is pure
+ * Python and reaches its native code through third-party wheels; each entry point below names the
+ * reference call site (file:line under the reference repo) whose native work it replaces.  The Python
+ * host side (intool-rag_amd/hiprag/_native.py) binds exactly these symbols with ctypes; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = OK, <0 = HIPRAG_E_*; hiprag_last_error() gives a
+ *     thread-local message for the last failure on the calling thread.
+ *   - handles are opaque uint64; the library owns all device memory behind a handle until *_destroy.
+ *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*); they enqueue work and return
+ *     without synchronising.  Non-"_dev" variants take HOST pointers, copy, run and synchronise.
+ *   - callers may call from any thread (asyncio.to_thread workers, rag/providers/hf/embeddings.py:53,76):
+ *     each handle serialises its own calls with an internal mutex and sets its device on entry.
+ *   - no Python callbacks, no exceptions across the boundary, no torch types.
+ */
+#ifndef HIPRAG_H
+#define HIPRAG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPRAG_OK 0
+#define HIPRAG_E_INVALID (-1)  /* bad argument */
+#define HIPRAG_E_HIP (-2)      /* HIP runtime error (message has hipGetErrorString) */
+#define HIPRAG_E_HANDLE (-3)   /* unknown / destroyed handle */
+#define HIPRAG_E_IO (-4)       /* file error */
+#define HIPRAG_E_NOMEM (-5)
+#define HIPRAG_E_UNSUPPORTED (-6)
+
+#define HIPRAG_METRIC_IP 0 /* larger score first  (faiss.IndexFlatIP order)  */
+#define HIPRAG_METRIC_L2 1 /* smaller squared-L2 first (faiss.IndexFlatL2 order; rag/storage/faiss_index.py:123) */
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int32_t hiprag_version(void);
+const char* hiprag_last_error(void);
+int32_t hiprag_device_count(int32_t* out_count);
+int32_t hiprag_device_sync(int32_t device);
+
+/* HIP-event timing on an arbitrary stream (bench.py measures kernels on the stream they run on). */
+int32_t hiprag_event_create(uint64_t* out_event);
+int32_t hiprag_event_record(uint64_t event, void* stream);
+int32_t hiprag_event_elapsed_ms(uint64_t start, uint64_t stop, float* out_ms); /* synchronises on stop */
+int32_t hiprag_event_destroy(uint64_t event);
+
+/* ---- dense flat index (replaces faiss.IndexFlatL2 / IndexFlatIP) -------------------------------------
+ * create   <- faiss.IndexFlatL2(d)                      rag/storage/faiss_index.py:123
+ * add      <- index.add(float32[n,d])                   rag/storage/faiss_index.py:124
+ * search   <- index.search(float32[nq,d], k)            rag/storage/faiss_index.py:83, rag/agent/search_engine.py:45
+ * ntotal/d <- index.ntotal / index.d                    rag/storage/faiss_index.py:97,103
+ * save/load<- faiss.write_index / faiss.read_index      rag/storage/faiss_index.py:133,54
+ *
+ * Results: exact top-k under (better score first, lower id first on ties), where the score of a row is the
+ * fp64-accumulated inner product / squared L2 distance of the fp32 inputs; out_scores is that value rounded
+ * to fp32.  Slots past ntotal are padded FAISS-style: id -1, score -FLT_MAX (IP) / FLT_MAX (L2).
+ * Returned ids are row numbers in insertion order plus the index's id_base (row-sharded indices).
+ * Inputs must be finite.
+ */
+int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_handle);
+int32_t hipidx_destroy(uint64_t h);
+int32_t hipidx_add(uint64_t h, const float* x_host, int64_t n);
+int32_t hipidx_add_dev(uint64_t h, const float* x_dev, int64_t n, void* stream);
+int32_t hipidx_ntotal(uint64_t h, int64_t* out_n);
+int32_t hipidx_dim(uint64_t h, int32_t* out_d);
+int32_t hipidx_metric(uint64_t h, int32_t* out_metric);
+int32_t hipidx_set_id_base(uint64_t h, int64_t id_base);
+int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, float* out_scores, int64_t* out_ids);
+/* device variant: out_scores64_dev [nq,k] double (exact, for cross-shard merges), out_scores_dev [nq,k]
+ * float (may be NULL), out_ids_dev [nq,k] int64. */
+int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
+                          float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+/* make sure search workspace for (nq<=32 per pass, k) exists so that search_dev never allocates */
+int32_t hipidx_reserve_search(uint64_t h, int32_t k);
+int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host); /* row as stored (tests, export) */
+int32_t hipidx_save(uint64_t h, const char* path);
+int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle);
+
+typedef struct hipidx_stats {
+    int64_t passes;            /* scan launches so far (one per <=32 queries) */
+    int64_t queries;           /* queries answered */
+    int64_t fallback_queries;  /* queries whose fast-path certificate failed and took the exhaustive path */
+    int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
+    float last_scan_ms;        /* HIP-event time of the last scan kernel if timing was enabled, else -1 */
+} hipidx_stats;
+int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
+int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* records events around the scan kernel; get_stats syncs */
+
+/* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
+ * in_scores64 / in_ids: [n_parts, nq, k_in] (device).  Canonical comparator as above; ids < 0 are padding.
+ * New capability (the reference is single-process); correctness criterion: sharded == unsharded, bit for bit. */
+int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_ids_dev, int32_t n_parts, int32_t nq,
+                              int32_t k_in, int32_t k_out, int32_t metric, double* out_scores64_dev,
+                              float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* ---- BM25 term-at-a-time sparse scoring (named by the reference's README.md:54-58 and rag/config.py:43-45,
+ *      implemented nowhere in it; spec in DESIGN.md) -------------------------------------------------------
+ * Postings are CSR over term ids, doc ids ascending inside a list, impacts precomputed in fp32 by the host.
+ * score(doc) = sum over query terms IN QUERY ORDER of impact (fp32 adds); docs with score <= 0 are excluded;
+ * order (score desc, doc id asc); padding id -1 / score -FLT_MAX. */
+int32_t hipbm25_create(int64_t n_docs, int64_t n_terms, const uint64_t* offsets_host, const uint32_t* doc_ids_host,
+                       const float* impacts_host, int32_t device, uint64_t* out_handle);
+int32_t hipbm25_destroy(uint64_t h);
+int32_t hipbm25_set_id_base(uint64_t h, int64_t id_base);
+int32_t hipbm25_search(uint64_t h, const uint32_t* term_ids_host, const int32_t* q_offsets_host, int32_t nq, int32_t k,
+                       float* out_scores, int64_t* out_ids);
+int32_t hipbm25_search_dev(uint64_t h, const uint32_t* term_ids_host, const int32_t* q_offsets_host, int32_t nq,
+                           int32_t k, double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev,
+                           void* stream);
+typedef struct hipbm25_stats {
+    int64_t queries;
+    int64_t postings_touched; /* sum of df over all query terms so far */
+    int64_t bytes_algorithmic; /* 8 B per posting + 2*4*N per query (zero + select read) */
+} hipbm25_stats;
+int32_t hipbm25_get_stats(uint64_t h, hipbm25_stats* out);
+
+/* ---- reciprocal-rank fusion (README.md:54-58 "hybrid"; weights rag/config.py:44-45) ---------------------
+ * s(d) = w_a/(c + rank_a(d)) + w_b/(c + rank_b(d)), ranks 1-based, a missing list contributes +0;
+ * IEEE fp32 in exactly that order; order (s desc, id asc); ids < 0 in the inputs are padding. */
+int32_t hiprrf_fuse(const int64_t* ids_a_host, const int64_t* ids_b_host, int32_t nq, int32_t depth_a, int32_t depth_b,
+                    int32_t k, float c, float w_a, float w_b, float* out_scores, int64_t* out_ids);
+int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int32_t nq, int32_t depth_a,
+                        int32_t depth_b, int32_t k, float c, float w_a, float w_b, float* out_scores_dev,
+                        int64_t* out_ids_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPRAG_H */

@@ -1,0 +1,938 @@
+// dense_index.hip -- flat (brute-force) vector index for MI355X / gfx950.
+//
+// Replaces faiss.IndexFlatL2 / IndexFlatIP as used by the reference:
+//   build   rag/storage/faiss_index.py:121-124   (np.array(float32) -> IndexFlatL2(d).add)
+//   search  rag/storage/faiss_index.py:81-83     (index.search(float32[1,d], k))
+//
+// Data layout in HBM (ours, not FAISS's): rows are stored in 32-row BLOCKS, each block as P = d_pad/8 PIECES of
+// 1 KiB.  Piece p of block B holds, for lane = h*32 + r (h in {0,1}, r in 0..31), the four floats
+// X[32B + r][8p + 4h + 0..3].  That is exactly the A-operand fragment of four consecutive
+// v_mfma_f32_32x32x2_f32 instructions, so the scan reads the index with fully coalesced 16-B-per-lane loads
+// straight into MFMA operand registers: no LDS staging, no transposes, and one wave's work is one contiguous
+// 1 KiB * P run per block.  d_pad is d rounded up to 128 floats (zero filled).
+//
+// One search pass answers up to 32 queries (the N dimension of the 32x32 MFMA tile):
+//   K1  scan_kernel     every wave streams a contiguous range of blocks; queries sit in LDS in B-fragment order;
+//                       exact-fp32 MFMA (a k-ordered fmaf chain) gives a 32 rows x 32 queries score tile; the
+//                       epilogue keeps only max-over-4-rows ("group maxima") -> gmax[query][group]  (N/4 floats/query)
+//   K2a select_kernel   per (query, 4096-group chunk): exact top-(K'+1) of the group maxima
+//   K2b finish_kernel   per query: merge chunk winners -> K' best groups, re-score their 4*K' rows in fp64 from the
+//                       fp32 data, exact top-k under (score, id); then a CERTIFICATE: every row outside the K' groups
+//                       has fp32 score <= m (the (K'+1)-th group maximum), hence exact score <= m + eps, eps a
+//                       worst-case bound of the fp32 chain error.  If the k-th exact score is not > m + eps the
+//                       query is flagged and
+//   K2c/K2d exhaustive  (launched always, exit at once unless flagged) re-score EVERY row in fp64 and select.
+// So results are exact for any input (ties, duplicates, zero vectors), and the common case reads the index once.
+//
+// Bound: HBM.  Algorithmic bytes per pass = nblocks * P * 1024 (+ norms in L2 mode) -- hipidx_stats.bytes_per_pass.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "topk_device.h"
+
+namespace hiprag {
+namespace {
+
+constexpr int kRowsPerBlock = 32;
+constexpr int kPieceFloats = 256;
+constexpr int kPieceVec4 = 64;
+constexpr int kMaxQ = 32;          // queries per pass
+constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
+constexpr int kSelThreads = 256;
+constexpr int kRing = 16;          // pieces in flight per wave (16 KiB)
+constexpr int kExRows = 4096;      // rows per workgroup in the exhaustive path
+constexpr int kMaxK = 1000;
+constexpr int kSlackGroups = 6;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------
+// build: row-major -> blocked layout, squared norms
+// ------------------------------------------------------------------------------------------------------
+__global__ void retile_kernel(const float* __restrict__ src, int64_t row0, int64_t n, int d, int P,
+                              float4* __restrict__ xb)
+{
+    const int64_t blk0 = row0 / kRowsPerBlock;
+    const int64_t nblk = (row0 + n - 1) / kRowsPerBlock - blk0 + 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * P * kPieceVec4) return;
+    const int lane = (int)(t & 63);
+    const int64_t pp = t >> 6;
+    const int p = (int)(pp % P);
+    const int64_t blk = blk0 + pp / P;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row = blk * kRowsPerBlock + r;
+    if (row < row0 || row >= row0 + n) return;
+    const int col = 8 * p + 4 * h;
+    const float* s = src + (row - row0) * (int64_t)d + col;
+    float4 v;
+    v.x = col + 0 < d ? s[0] : 0.f;
+    v.y = col + 1 < d ? s[1] : 0.f;
+    v.z = col + 2 < d ? s[2] : 0.f;
+    v.w = col + 3 < d ? s[3] : 0.f;
+    xb[(blk * P + p) * kPieceVec4 + lane] = v;
+}
+
+__global__ void untile_kernel(const float4* __restrict__ xb, int64_t row0, int64_t n, int d, int P,
+                              float* __restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_row = (int64_t)P * 2;
+    if (t >= n * per_row) return;
+    const int64_t row = row0 + t / per_row;
+    const int ph = (int)(t % per_row);
+    const int p = ph >> 1, h = ph & 1;
+    const int64_t blk = row / kRowsPerBlock;
+    const int r = (int)(row % kRowsPerBlock);
+    float4 v = xb[(blk * P + p) * kPieceVec4 + h * 32 + r];
+    const int col = 8 * p + 4 * h;
+    float* o = dst + (row - row0) * (int64_t)d + col;
+    if (col + 0 < d) o[0] = v.x;
+    if (col + 1 < d) o[1] = v.y;
+    if (col + 2 < d) o[2] = v.z;
+    if (col + 3 < d) o[3] = v.w;
+}
+
+// one wave per row: fp64 sum of squares -> float; running max of squared norm (float bits, non-negative)
+__global__ void norms_kernel(const float* __restrict__ src, int64_t row0, int64_t n, int d, float* __restrict__ norms,
+                             unsigned* __restrict__ max_norm2_bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* s = src + row * (int64_t)d;
+    double acc = 0.0;
+    for (int c = lane; c < d; c += 64) { double v = (double)s[c]; acc += v * v; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        float f = (float)acc;
+        norms[row0 + row] = f;
+        // round up so the stored maximum is an upper bound of the exact value
+        float up = (double)f < acc ? nextafterf(f, INFINITY) : f;
+        atomicMax(max_norm2_bits, __float_as_uint(up));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1: the scan
+// ------------------------------------------------------------------------------------------------------
+struct ScanArgs {
+    const float4* xb;     // blocked index
+    const float* q;       // [nq, d] row-major
+    const float* norms;   // [rows] squared norms (L2 only)
+    float* gmax;          // [kMaxQ, gstride] group maxima
+    int64_t gstride;
+    int64_t nblocks;
+    int64_t ntotal;
+    int nq, d, P;
+};
+
+template <int METRIC, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
+{
+    extern __shared__ float4 qs[];  // [P][64] query fragments: lane = h*32 + b holds Q[b][8p + 4h + 0..3]
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> block ranges live in SGPRs
+    const int P = a.P;
+
+    for (int idx = tid; idx < P * kPieceVec4; idx += NT) {
+        const int p = idx >> 6, l = idx & 63;
+        const int b = l & 31, h = l >> 5;
+        const int col = 8 * p + 4 * h;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.nq) {
+            const float* s = a.q + (int64_t)b * a.d + col;
+            if (col + 0 < a.d) v.x = s[0];
+            if (col + 1 < a.d) v.y = s[1];
+            if (col + 2 < a.d) v.z = s[2];
+            if (col + 3 < a.d) v.w = s[3];
+        }
+        qs[idx] = v;
+    }
+    __syncthreads();
+
+    // contiguous block range of this wave
+    const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave;
+    const int64_t W = (int64_t)gridDim.x * NWAVES;
+    const int64_t b0 = gw * a.nblocks / W;
+    const int64_t b1 = (gw + 1) * a.nblocks / W;
+    if (b1 <= b0) return;
+    const int S = (int)((b1 - b0) * P);  // pieces in this wave's stream
+    const float4* base = a.xb + b0 * P * kPieceVec4;  // wave-uniform; lanes add 16 B each through the VGPR offset
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int h = lane >> 5, qb = lane & 31;
+
+    // The X stream is driven by hand: loads are inline asm (invisible to hipcc's waitcnt pass, which otherwise drains
+    // the queue with vmcnt(0) at the loop back-edge) and every use is fenced by a counted s_waitcnt that takes the
+    // ring slot as an in/out operand, so no consumer can be scheduled above its wait.  vmcnt(kRing-1) before slot i is
+    // exact when only the ring is in flight and merely conservative when the epilogue's store / norm loads are queued too.
+    f32x4 ring[kRing];
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) {
+        const unsigned voff = lane16 + (unsigned)min(i, S - 1) * 1024u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+    }
+
+    int s = 0;
+    float4 bnext = qs[lane];
+    for (int64_t blk = b0; blk < b1; ++blk) {
+        f32x4 nrm[4];
+        if (METRIC == HIPRAG_METRIC_L2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* np = a.norms + blk * kRowsPerBlock + 8 * g + 4 * h;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nrm[g]) : "v"(np) : "memory");
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int pp = 0; pp < P; pp += kRing) {
+#pragma unroll
+            for (int i = 0; i < kRing; ++i) {
+                // one step = one 1 KiB piece: 4 MFMAs on the piece loaded kRing steps ago, then re-arm its ring slot
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[i]) : "n"(kRing - 1) : "memory");
+                const f32x4 av = ring[i];
+                const float4 bv = bnext;
+                int nx = pp + i + 1;
+                nx = nx == P ? 0 : nx;
+                bnext = qs[nx * kPieceVec4 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
+                const unsigned voff = lane16 + (unsigned)min(s + kRing + i, S - 1) * 1024u;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s += kRing;
+        }
+        // epilogue: acc[4g + j] = <x_row, q_qb>, row = 32*blk + 8g + 4h + j
+        float sc[16];
+        if (METRIC == HIPRAG_METRIC_L2) {
+            // the 4 norm loads were issued before this block's P >= kRing ring re-arms: all but the kRing youngest done
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(kRing) : "memory");
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sc[4 * g + 0] = 2.f * acc[4 * g + 0] - nrm[g][0];
+                sc[4 * g + 1] = 2.f * acc[4 * g + 1] - nrm[g][1];
+                sc[4 * g + 2] = 2.f * acc[4 * g + 2] - nrm[g][2];
+                sc[4 * g + 3] = 2.f * acc[4 * g + 3] - nrm[g][3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = acc[i];
+        }
+        if ((blk + 1) * kRowsPerBlock > a.ntotal) {  // padded tail rows never compete
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t row = blk * kRowsPerBlock + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (row >= a.ntotal) sc[i] = -INFINITY;
+            }
+        }
+        f32x4 o;
+        o[0] = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        o[1] = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
+        o[2] = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
+        o[3] = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
+        // group index = blk*8 + h*4 + g  <->  rows 32*blk + 8g + 4h + 0..3
+        // A plain store: with the ring loads hidden in asm it is the only VMEM op hipcc sees here, so it never
+        // makes the compiler drain the queue; in the hand-counted vmcnt it is one extra YOUNGER op (conservative).
+        float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(a.gmax + (int64_t)qb * a.gstride + blk * 8 + h * 4) = o4;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's clamped re-arms are still in flight
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp64 re-scoring of one 4-row group straight from the blocked layout (wave-wide; result for row r0 + (lane&3)
+// is returned in every lane with that low index).  The summation order depends only on the row's contents.
+// ------------------------------------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ double rescore4(const float4* __restrict__ xb, int P, int64_t blk, int r0,
+                                           const float* __restrict__ qv /* LDS, d_pad floats, zero padded */)
+{
+    const int lane = threadIdx.x & 63;
+    const int rr = lane & 3, hh = (lane >> 2) & 1, pq = lane >> 3;
+    const float4* src = xb + blk * P * kPieceVec4 + hh * 32 + r0 + rr;
+    double acc = 0.0;
+    for (int p = pq; p < P; p += 8) {
+        const float4 x = src[p * kPieceVec4];
+        const float* qq = qv + 8 * p + 4 * hh;
+        if (METRIC == HIPRAG_METRIC_IP) {
+            acc += (double)x.x * (double)qq[0];
+            acc += (double)x.y * (double)qq[1];
+            acc += (double)x.z * (double)qq[2];
+            acc += (double)x.w * (double)qq[3];
+        } else {
+            double t;
+            t = (double)x.x - (double)qq[0]; acc += t * t;
+            t = (double)x.y - (double)qq[1]; acc += t * t;
+            t = (double)x.z - (double)qq[2]; acc += t * t;
+            t = (double)x.w - (double)qq[3]; acc += t * t;
+        }
+    }
+#pragma unroll
+    for (int off = 4; off <= 32; off <<= 1) acc += __shfl_xor(acc, off);
+    return acc;
+}
+
+struct FinishArgs {
+    const float4* xb;
+    const float* q;            // [nq, d]
+    const u64* ck;             // [nq, nchunks*K1]
+    const i64* ci;
+    const unsigned* max_norm2_bits;
+    double* out64;             // [nq, k]
+    float* out32;              // [nq, k] or null
+    int64_t* out_ids;          // [nq, k]
+    int* flags;                // [nq]
+    unsigned long long* fallback_counter;
+    int64_t ntotal, id_base, ncand;  // ncand = nchunks*K1
+    int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
+};
+
+template <int METRIC>
+__device__ __forceinline__ void write_result(double* out64, float* out32, int64_t* out_ids, int64_t o, u64 key, i64 id,
+                                             int64_t id_base)
+{
+    double s;
+    if (key == 0) {
+        s = METRIC == HIPRAG_METRIC_IP ? -DBL_MAX : DBL_MAX;
+        out_ids[o] = -1;
+        if (out32) out32[o] = METRIC == HIPRAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
+    } else {
+        s = METRIC == HIPRAG_METRIC_IP ? unord64(key) : -unord64(key);
+        out_ids[o] = id + id_base;
+        if (out32) out32[o] = (float)s;
+    }
+    out64[o] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2b: per query -- merge chunk winners, re-score K' groups in fp64, final top-k, certificate
+// ------------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
+{
+    extern __shared__ unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
+    u64* selk = reinterpret_cast<u64*>(ids + kSelChunk);
+    const int K1 = a.Kp + 1;
+    i64* seli = reinterpret_cast<i64*>(selk + K1);
+    KeyId* red = reinterpret_cast<KeyId*>(seli + K1);
+    double* dred = reinterpret_cast<double*>(red + 2 * (kSelThreads / 64));
+    u64& kth_key = *reinterpret_cast<u64*>(dred + kSelThreads / 64);  // all LDS in the one dynamic array
+    float* qv = reinterpret_cast<float*>(dred + kSelThreads / 64 + 1);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int dpad = a.P * 8;
+
+    // query into LDS (zero padded) and its exact squared norm
+    double qpart = 0.0;
+    for (int c = tid; c < dpad; c += kSelThreads) {
+        float v = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+        qv[c] = v;
+        qpart += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
+    if (lane == 0) dred[wave] = qpart;
+    if (tid == 0) kth_key = 0;
+    __syncthreads();
+    double qn2 = 0.0;
+    for (int w = 0; w < kSelThreads / 64; ++w) qn2 += dred[w];
+
+    {
+        const u64* sk = a.ck + (int64_t)q * a.ncand;
+        const i64* si = a.ci + (int64_t)q * a.ncand;
+        wg_stream_topk<kSelThreads>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, a.ncand, K1, keys, ids, red,
+                                    selk, seli);
+    }
+
+    // re-score the K' selected groups (4 rows each)
+    for (int j = wave; j < a.Kp; j += kSelThreads / 64) {
+        const u64 gk = selk[j];
+        const i64 gi = seli[j];
+        u64 key = 0;
+        i64 row = -1;
+        if (gk != 0) {
+            const int64_t blk = gi >> 3;
+            const int r0 = 8 * (int)(gi & 3) + 4 * (int)((gi >> 2) & 1);
+            const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+            row = blk * kRowsPerBlock + r0 + (lane & 3);
+            if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+        }
+        if (lane < 4) { keys[j * 4 + lane] = key; ids[j * 4 + lane] = row; }
+    }
+    __syncthreads();
+
+    const int64_t ob = (int64_t)q * a.k;
+    wg_topk_rounds<kSelThreads>(keys, ids, a.Kp * 4, a.k, red, [&](int r, u64 k, i64 id) {
+        write_result<METRIC>(a.out64, a.out32, a.out_ids, ob + r, k, id, a.id_base);
+        if (r == a.k - 1) kth_key = k;
+    });
+
+    if (tid == 0) {
+        int flag = 0;
+        const u64 bk = selk[a.Kp];  // best group NOT re-scored
+        if (bk != 0) {
+            const float m = unord32((u32)(bk >> 32));
+            if (m != -INFINITY) {
+                const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
+                const double qn = sqrt(qn2);
+                const double u = 5.9604644775390625e-08;  // 2^-24
+                double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
+                double kth_sel;  // k-th exact score on the scale the scan selects by
+                if (METRIC == HIPRAG_METRIC_IP) {
+                    kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
+                } else {
+                    eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
+                    kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;  // 2<x,q> - |x|^2 = |q|^2 - dist
+                    eps += 4.0 * u * qn2;                                        // rounding of qn2 - dist itself
+                }
+                if (!(kth_sel > (double)m + eps)) flag = 1;
+            }
+        }
+        a.flags[q] = flag;
+        if (flag) atomicAdd(a.fallback_counter, 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2c / K2d: exhaustive exact path for flagged queries (exit immediately otherwise)
+// ------------------------------------------------------------------------------------------------------
+struct ExArgs {
+    const float4* xb;
+    const float* q;
+    const int* flags;
+    u64* ek;       // [nq, nslices*kk]
+    i64* ei;
+    double* out64;
+    float* out32;
+    int64_t* out_ids;
+    int64_t ntotal, id_base;
+    int d, P, k, kk, nslices;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(kSelThreads) void exhaustive_scan_kernel(ExArgs a)
+{
+    const int q = blockIdx.y;
+    if (!a.flags[q]) return;
+    extern __shared__ unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
+    KeyId* red = reinterpret_cast<KeyId*>(ids + kSelChunk);
+    float* qv = reinterpret_cast<float*>(red + 2 * (kSelThreads / 64));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dpad = a.P * 8;
+    for (int c = tid; c < dpad; c += kSelThreads) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+    __syncthreads();
+    const int64_t row_base = (int64_t)blockIdx.x * kExRows;
+    const int nrows = (int)min((int64_t)kExRows, a.ntotal - row_base);
+    for (int g = wave; g * 4 < kExRows; g += kSelThreads / 64) {
+        const int64_t row0 = row_base + (int64_t)g * 4;
+        u64 key = 0;
+        const int64_t row = row0 + (lane & 3);
+        if (row0 < a.ntotal) {
+            const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
+            if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+        }
+        if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
+    }
+    __syncthreads();
+    u64* ok = a.ek + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
+    i64* oi = a.ei + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
+    wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(kSelThreads) void exhaustive_merge_kernel(ExArgs a)
+{
+    const int q = blockIdx.x;
+    if (!a.flags[q]) return;
+    extern __shared__ unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
+    u64* selk = reinterpret_cast<u64*>(ids + kSelChunk);
+    i64* seli = reinterpret_cast<i64*>(selk + a.k);
+    KeyId* red = reinterpret_cast<KeyId*>(seli + a.k);
+    const int64_t M = (int64_t)a.nslices * a.kk;
+    const u64* sk = a.ek + (int64_t)q * M;
+    const i64* si = a.ei + (int64_t)q * M;
+    wg_stream_topk<kSelThreads>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, M, a.k, keys, ids, red, selk, seli);
+    for (int r = threadIdx.x; r < a.k; r += kSelThreads)
+        write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + r, selk[r], seli[r], a.id_base);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host object
+// ------------------------------------------------------------------------------------------------------
+struct DenseIndex {
+    std::mutex mu;
+    int device = 0;
+    int d = 0, P = 0, metric = 0;
+    int64_t ntotal = 0, cap_blocks = 0, id_base = 0;
+    int n_cu = 256;
+    DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
+    // search workspace
+    DevBuf gmax, ck, ci, flags, ek, ei, qbuf, o64, o32, oid;
+    int ws_k = 0;
+    int64_t ws_blocks = 0;
+    // stats
+    int64_t passes = 0, queries = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+
+    int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
+    unsigned* max_norm2_bits() { return scalars.as<unsigned>(); }
+    unsigned long long* fallback_counter() { return reinterpret_cast<unsigned long long*>(scalars.as<unsigned>() + 2); }
+
+    ~DenseIndex()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+
+    int32_t init()
+    {
+        HR_CHECK_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int32_t rc = scalars.reserve(64);
+        if (rc) return rc;
+        HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
+        return HIPRAG_OK;
+    }
+
+    int32_t grow(int64_t need_blocks)
+    {
+        if (need_blocks <= cap_blocks) return HIPRAG_OK;
+        int64_t nc = cap_blocks == 0 ? need_blocks : std::max(need_blocks, cap_blocks + cap_blocks / 2);
+        size_t xbytes = (size_t)nc * P * kPieceFloats * sizeof(float);
+        size_t nbytes = (size_t)nc * kRowsPerBlock * sizeof(float);
+        void* nx = nullptr;
+        void* nn = nullptr;
+        HR_CHECK_HIP(hipMalloc(&nx, xbytes));
+        hipError_t e = hipMalloc(&nn, nbytes);
+        if (e != hipSuccess) { (void)hipFree(nx); HR_CHECK_HIP(e); }
+        HR_CHECK_HIP(hipMemset(nx, 0, xbytes));
+        HR_CHECK_HIP(hipMemset(nn, 0, nbytes));
+        if (xb.p) {
+            HR_CHECK_HIP(hipMemcpy(nx, xb.p, (size_t)cap_blocks * P * kPieceFloats * sizeof(float), hipMemcpyDeviceToDevice));
+            HR_CHECK_HIP(hipMemcpy(nn, norms.p, (size_t)cap_blocks * kRowsPerBlock * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+        xb.release();
+        norms.release();
+        xb.p = nx; xb.bytes = xbytes;
+        norms.p = nn; norms.bytes = nbytes;
+        cap_blocks = nc;
+        return HIPRAG_OK;
+    }
+
+    // x_dev: [n,d] row-major on this device
+    int32_t add_dev(const float* x_dev, int64_t n, hipStream_t st)
+    {
+        if (n == 0) return HIPRAG_OK;
+        int32_t rc = grow((ntotal + n + kRowsPerBlock - 1) / kRowsPerBlock);
+        if (rc) return rc;
+        const int64_t blk0 = ntotal / kRowsPerBlock;
+        const int64_t nblk = (ntotal + n - 1) / kRowsPerBlock - blk0 + 1;
+        const int64_t threads = nblk * P * kPieceVec4;
+        hipLaunchKernelGGL(retile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x_dev, ntotal, n, d, P,
+                           xb.as<float4>());
+        hipLaunchKernelGGL(norms_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x_dev, ntotal, n, d,
+                           norms.as<float>(), max_norm2_bits());
+        HR_CHECK_HIP(hipGetLastError());
+        ntotal += n;
+        return HIPRAG_OK;
+    }
+
+    int32_t add_host(const float* x, int64_t n)
+    {
+        if (n == 0) return HIPRAG_OK;
+        const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)d * 4));
+        DevBuf stage;
+        int32_t rc = stage.reserve((size_t)std::min(chunk_rows, n) * d * sizeof(float));
+        if (rc) return rc;
+        rc = grow((ntotal + n + kRowsPerBlock - 1) / kRowsPerBlock);
+        if (rc) return rc;
+        for (int64_t o = 0; o < n; o += chunk_rows) {
+            const int64_t m = std::min(chunk_rows, n - o);
+            HR_CHECK_HIP(hipMemcpy(stage.p, x + o * d, (size_t)m * d * sizeof(float), hipMemcpyHostToDevice));
+            rc = add_dev(stage.as<float>(), m, nullptr);
+            if (rc) return rc;
+            HR_CHECK_HIP(hipStreamSynchronize(nullptr));
+        }
+        return HIPRAG_OK;
+    }
+
+    static int kprime(int k) { return k + kSlackGroups; }
+
+    int32_t reserve_search(int k)
+    {
+        const int64_t nb = std::max<int64_t>(nblocks(), 1);
+        if (k <= ws_k && nb <= ws_blocks) return HIPRAG_OK;
+        const int kk = std::max(k, ws_k);
+        const int64_t nbb = std::max(nb, ws_blocks);
+        const int64_t gstride = nbb * 8;
+        const int64_t nchunks = (gstride + kSelChunk - 1) / kSelChunk;
+        const int K1 = kprime(kk) + 1;
+        const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
+        const int ekk = std::min(kk, kExRows);
+        int32_t rc;
+        if ((rc = gmax.reserve((size_t)kMaxQ * gstride * sizeof(float)))) return rc;
+        if ((rc = ck.reserve((size_t)kMaxQ * nchunks * K1 * sizeof(u64)))) return rc;
+        if ((rc = ci.reserve((size_t)kMaxQ * nchunks * K1 * sizeof(i64)))) return rc;
+        if ((rc = flags.reserve(kMaxQ * sizeof(int)))) return rc;
+        if ((rc = ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
+        if ((rc = ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
+        ws_k = kk;
+        ws_blocks = nbb;
+        return HIPRAG_OK;
+    }
+
+    template <int METRIC>
+    int32_t run_pass(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        const int64_t nb = nblocks();
+        const int64_t gstride = ws_blocks * 8;
+        const int64_t ngroups = nb * 8;
+        const int Kp = kprime(k), K1 = Kp + 1;
+        const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
+
+        ScanArgs sa;
+        sa.xb = xb.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = gmax.as<float>();
+        sa.gstride = gstride; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
+        constexpr int NW = 8;
+        auto scan = scan_kernel<METRIC, NW>;
+        const size_t scan_lds = (size_t)P * 1024;
+        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)scan_lds));
+        if (timing) HR_CHECK_HIP(hipEventRecord(ev0, st));
+        if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
+        if (timing) { HR_CHECK_HIP(hipEventRecord(ev1, st)); ev_valid = true; }
+
+        hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
+                           (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, ck.as<u64>(), ci.as<i64>());
+
+        FinishArgs fa;
+        fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = ck.as<u64>(); fa.ci = ci.as<i64>();
+        fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
+        fa.flags = flags.as<int>(); fa.fallback_counter = fallback_counter();
+        fa.ntotal = ntotal; fa.id_base = id_base; fa.ncand = nchunks * K1; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp;
+        const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
+                               (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
+        auto fin = finish_kernel<METRIC>;
+        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)fin_lds));
+        hipLaunchKernelGGL(fin, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
+
+        ExArgs ea;
+        ea.xb = xb.as<float4>(); ea.q = q_dev; ea.flags = flags.as<int>(); ea.ek = ek.as<u64>(); ea.ei = ei.as<i64>();
+        ea.out64 = o64p; ea.out32 = o32p; ea.out_ids = oidp; ea.ntotal = ntotal; ea.id_base = id_base;
+        ea.d = d; ea.P = P; ea.k = k; ea.kk = std::min(k, kExRows);
+        ea.nslices = (int)std::max<int64_t>(1, (ntotal + kExRows - 1) / kExRows);
+        const size_t ex_lds = (size_t)kSelChunk * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) + (size_t)P * 8 * sizeof(float);
+        auto exs = exhaustive_scan_kernel<METRIC>;
+        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)ex_lds));
+        hipLaunchKernelGGL(exs, dim3(ea.nslices, nq), dim3(kSelThreads), ex_lds, st, ea);
+        const size_t em_lds = (size_t)kSelChunk * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId);
+        auto exm = exhaustive_merge_kernel<METRIC>;
+        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)em_lds));
+        hipLaunchKernelGGL(exm, dim3(nq), dim3(kSelThreads), em_lds, st, ea);
+        HR_CHECK_HIP(hipGetLastError());
+        ++passes;
+        queries += nq;
+        return HIPRAG_OK;
+    }
+
+    int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        int32_t rc = reserve_search(k);
+        if (rc) return rc;
+        if (timing && !ev0) {
+            HR_CHECK_HIP(hipEventCreate(&ev0));
+            HR_CHECK_HIP(hipEventCreate(&ev1));
+        }
+        for (int o = 0; o < nq; o += kMaxQ) {
+            const int m = std::min(kMaxQ, nq - o);
+            float* o32q = o32p ? o32p + (int64_t)o * k : nullptr;
+            rc = metric == HIPRAG_METRIC_IP
+                     ? run_pass<HIPRAG_METRIC_IP>(q_dev + (int64_t)o * d, m, k, o64p + (int64_t)o * k, o32q,
+                                                  oidp + (int64_t)o * k, st)
+                     : run_pass<HIPRAG_METRIC_L2>(q_dev + (int64_t)o * d, m, k, o64p + (int64_t)o * k, o32q,
+                                                  oidp + (int64_t)o * k, st);
+            if (rc) return rc;
+        }
+        return HIPRAG_OK;
+    }
+};
+
+Registry<DenseIndex>& reg()
+{
+    static Registry<DenseIndex> r;
+    return r;
+}
+
+#define GET_INDEX(h)                                                       \
+    std::shared_ptr<DenseIndex> ix = reg().get(h);                         \
+    if (!ix) { set_error("unknown dense index handle %llu", (unsigned long long)(h)); return HIPRAG_E_HANDLE; } \
+    std::lock_guard<std::mutex> guard(ix->mu);                             \
+    HR_CHECK_HIP(hipSetDevice(ix->device))
+
+}  // namespace
+}  // namespace hiprag
+
+using namespace hiprag;
+
+extern "C" {
+
+int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_handle)
+{
+    HR_REQUIRE(out_handle, "out_handle is null");
+    HR_REQUIRE(d > 0, "d must be positive (got %d)", d);
+    HR_REQUIRE(metric == HIPRAG_METRIC_IP || metric == HIPRAG_METRIC_L2, "unknown metric %d", metric);
+    const int P = ((d + 127) / 128) * 16;
+    if ((size_t)P * 1024 > 160 * 1024 - 1024) {
+        set_error("d=%d needs %d KiB of LDS for the query tile; the scan supports d <= 1152", d, P);
+        return HIPRAG_E_UNSUPPORTED;
+    }
+    auto ix = std::make_shared<DenseIndex>();
+    ix->device = device;
+    ix->d = d;
+    ix->P = P;
+    ix->metric = metric;
+    int32_t rc = ix->init();
+    if (rc) return rc;
+    *out_handle = reg().put(ix);
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_destroy(uint64_t h)
+{
+    std::shared_ptr<DenseIndex> ix = reg().get(h);
+    if (!ix) { set_error("unknown dense index handle"); return HIPRAG_E_HANDLE; }
+    {
+        std::lock_guard<std::mutex> guard(ix->mu);
+        (void)hipSetDevice(ix->device);
+        (void)hipDeviceSynchronize();
+    }
+    reg().erase(h);
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_add(uint64_t h, const float* x_host, int64_t n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(n >= 0 && (x_host || n == 0), "bad add arguments");
+    return ix->add_host(x_host, n);
+}
+
+int32_t hipidx_add_dev(uint64_t h, const float* x_dev, int64_t n, void* stream)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(n >= 0 && (x_dev || n == 0), "bad add arguments");
+    return ix->add_dev(x_dev, n, (hipStream_t)stream);
+}
+
+int32_t hipidx_ntotal(uint64_t h, int64_t* out_n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_n, "null out");
+    *out_n = ix->ntotal;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_dim(uint64_t h, int32_t* out_d)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_d, "null out");
+    *out_d = ix->d;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_metric(uint64_t h, int32_t* out_metric)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_metric, "null out");
+    *out_metric = ix->metric;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_set_id_base(uint64_t h, int64_t id_base)
+{
+    GET_INDEX(h);
+    ix->id_base = id_base;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_reserve_search(uint64_t h, int32_t k)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
+    return ix->reserve_search(k);
+}
+
+int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
+                          float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(nq >= 0, "nq < 0");
+    HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
+    if (nq == 0) return HIPRAG_OK;
+    HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
+    return ix->search_dev(q_dev, nq, k, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
+}
+
+int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, float* out_scores, int64_t* out_ids)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(nq >= 0, "nq < 0");
+    HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
+    if (nq == 0) return HIPRAG_OK;
+    HR_REQUIRE(q_host && out_scores && out_ids, "null pointer");
+    int32_t rc;
+    if ((rc = ix->qbuf.reserve((size_t)nq * ix->d * sizeof(float)))) return rc;
+    if ((rc = ix->o64.reserve((size_t)nq * k * sizeof(double)))) return rc;
+    if ((rc = ix->o32.reserve((size_t)nq * k * sizeof(float)))) return rc;
+    if ((rc = ix->oid.reserve((size_t)nq * k * sizeof(int64_t)))) return rc;
+    HR_CHECK_HIP(hipMemcpy(ix->qbuf.p, q_host, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice));
+    rc = ix->search_dev(ix->qbuf.as<float>(), nq, k, ix->o64.as<double>(), ix->o32.as<float>(), ix->oid.as<int64_t>(),
+                        nullptr);
+    if (rc) return rc;
+    HR_CHECK_HIP(hipMemcpy(out_scores, ix->o32.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+    HR_CHECK_HIP(hipMemcpy(out_ids, ix->oid.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_host, "null out");
+    HR_REQUIRE(row >= 0 && row < ix->ntotal, "row %lld out of range [0,%lld)", (long long)row, (long long)ix->ntotal);
+    DevBuf tmp;
+    int32_t rc = tmp.reserve((size_t)ix->d * sizeof(float));
+    if (rc) return rc;
+    const int64_t threads = (int64_t)ix->P * 2;
+    hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr, ix->xb.as<float4>(), row,
+                       (int64_t)1, ix->d, ix->P, tmp.as<float>());
+    HR_CHECK_HIP(hipGetLastError());
+    HR_CHECK_HIP(hipMemcpy(out_host, tmp.p, (size_t)ix->d * sizeof(float), hipMemcpyDeviceToHost));
+    return HIPRAG_OK;
+}
+
+// File format "HIPIDX01": magic[8], int32 d, int32 metric, int64 ntotal, then ntotal*d fp32 row-major.
+int32_t hipidx_save(uint64_t h, const char* path)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(path, "null path");
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("cannot open %s for writing", path); return HIPRAG_E_IO; }
+    const char magic[8] = {'H', 'I', 'P', 'I', 'D', 'X', '0', '1'};
+    int32_t hd[2] = {ix->d, ix->metric};
+    int64_t nt = ix->ntotal;
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(hd, 4, 2, f) == 2 && fwrite(&nt, 8, 1, f) == 1;
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(64ll << 20) / ((int64_t)ix->d * 4));
+    DevBuf tmp;
+    std::vector<float> host;
+    if (ok && nt > 0) {
+        int32_t rc = tmp.reserve((size_t)std::min(chunk, nt) * ix->d * sizeof(float));
+        if (rc) { fclose(f); return rc; }
+        host.resize((size_t)std::min(chunk, nt) * ix->d);
+    }
+    for (int64_t o = 0; ok && o < nt; o += chunk) {
+        const int64_t m = std::min(chunk, nt - o);
+        const int64_t threads = m * ix->P * 2;
+        hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr, ix->xb.as<float4>(), o, m,
+                           ix->d, ix->P, tmp.as<float>());
+        if (hipMemcpy(host.data(), tmp.p, (size_t)m * ix->d * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            fclose(f);
+            set_error("device read-back failed while saving");
+            return HIPRAG_E_HIP;
+        }
+        ok = fwrite(host.data(), sizeof(float), (size_t)m * ix->d, f) == (size_t)m * ix->d;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("write to %s failed", path); return HIPRAG_E_IO; }
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle)
+{
+    HR_REQUIRE(path && out_handle, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return HIPRAG_E_IO; }
+    char magic[8];
+    int32_t hd[2];
+    int64_t nt = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "HIPIDX01", 8) != 0 || fread(hd, 4, 2, f) != 2 ||
+        fread(&nt, 8, 1, f) != 1 || nt < 0) {
+        fclose(f);
+        set_error("%s is not a HIPIDX01 file", path);
+        return HIPRAG_E_IO;
+    }
+    uint64_t h = 0;
+    int32_t rc = hipidx_create(hd[0], hd[1], device, &h);
+    if (rc) { fclose(f); return rc; }
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(64ll << 20) / ((int64_t)hd[0] * 4));
+    std::vector<float> host((size_t)std::min(chunk, std::max<int64_t>(nt, 1)) * hd[0]);
+    for (int64_t o = 0; o < nt; o += chunk) {
+        const int64_t m = std::min(chunk, nt - o);
+        if (fread(host.data(), sizeof(float), (size_t)m * hd[0], f) != (size_t)m * hd[0]) {
+            fclose(f);
+            hipidx_destroy(h);
+            set_error("%s is truncated", path);
+            return HIPRAG_E_IO;
+        }
+        rc = hipidx_add(h, host.data(), m);
+        if (rc) { fclose(f); hipidx_destroy(h); return rc; }
+    }
+    fclose(f);
+    *out_handle = h;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_enable_timing(uint64_t h, int32_t on)
+{
+    GET_INDEX(h);
+    ix->timing = on != 0;
+    ix->ev_valid = false;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out, "null out");
+    HR_CHECK_HIP(hipDeviceSynchronize());
+    unsigned long long fb = 0;
+    HR_CHECK_HIP(hipMemcpy(&fb, ix->fallback_counter(), sizeof(fb), hipMemcpyDeviceToHost));
+    out->passes = ix->passes;
+    out->queries = ix->queries;
+    out->fallback_queries = (int64_t)fb;
+    out->bytes_per_pass = ix->nblocks() * ix->P * 1024 +
+                          (ix->metric == HIPRAG_METRIC_L2 ? ix->nblocks() * kRowsPerBlock * 4 : 0);
+    out->last_scan_ms = -1.f;
+    if (ix->timing && ix->ev_valid) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) == hipSuccess) out->last_scan_ms = ms;
+    }
+    return HIPRAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+"""
+GPU parity of the dense flat index (libhiprag hipidx_*) against the CPU oracle (fp64 truth, (score, id) order).
+Bar: ids bit-exact, scores within 1e-4 (they are fp64-rescored, so in practice within 1 ulp of fp32).
+Mirrors what the reference's path does: IndexFlatL2 build + search (rag/storage/faiss_index.py:81-83,121-124).
+"""
+import numpy as np
+import pytest
+
+from oracle import hybrid_oracle as ho
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+FLT_MAX = np.finfo(np.float32).max
+
+
+def _check(index, x, q, k, metric, id_base=0):
+    s, i = index.search(q, k)
+    es, ei = ho.flat_search(x, q, k, metric, id_base=id_base)
+    assert np.array_equal(i, ei), f"ids differ: first bad query {np.argwhere((i != ei).any(1))[:3].ravel()}"
+    valid = ei >= 0
+    assert np.allclose(s[valid], es[valid], rtol=0, atol=TOL)
+    pad = FLT_MAX if metric == ho.METRIC_L2 else -FLT_MAX
+    assert np.all(s[~valid] == pad)
+    return s, i
+
+
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+@pytest.mark.parametrize("n,d,nq,k", [(5000, 1024, 7, 10), (4097, 384, 33, 10), (1000, 768, 1, 50), (64, 16, 3, 5),
+                                      (31, 100, 2, 4), (20000, 1024, 32, 10)])
+def test_parity_random_unit_vectors(gpu, metric, n, d, nq, k):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(n, d, seed=1234)
+    q = ho.synthetic_queries(nq, d, seed=4321)
+    ix = HipFlatIndex(d, metric)
+    ix.add(x)
+    assert ix.ntotal == n
+    _check(ix, x, q, k, metric)
+    st = ix.stats()
+    assert st["queries"] == nq
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_unnormalised_and_scaled_vectors(gpu, metric):
+    from hiprag import HipFlatIndex
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3000, 256)) * rng.uniform(0.1, 30, size=(3000, 1))).astype(np.float32)
+    q = (rng.standard_normal((9, 256)) * 7).astype(np.float32)
+    ix = HipFlatIndex(256, metric)
+    ix.add(x)
+    s, i = ix.search(q, 10)
+    es, ei = ho.flat_search(x, q, 10, metric)
+    assert np.array_equal(i, ei)
+    assert np.allclose(s, es, rtol=1e-6, atol=TOL)
+
+
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_k_larger_than_ntotal_pads_with_minus_one(gpu, metric):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(5, 64, seed=1)
+    ix = HipFlatIndex(64, metric)
+    ix.add(x)
+    s, i = _check(ix, x, ho.synthetic_queries(2, 64), 8, metric)
+    assert np.all(i[:, 5:] == -1)
+
+
+def test_empty_index_returns_padding(gpu):
+    from hiprag import HipFlatIndex
+    ix = HipFlatIndex(32, "l2")
+    s, i = ix.search(np.zeros((2, 32), np.float32), 3)
+    assert np.all(i == -1) and np.all(s == FLT_MAX)
+
+
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_zero_query_is_all_ties_lowest_ids_win(gpu, metric):
+    """embed_single('') returns the zero vector (rag/providers/hf/embeddings.py:47-48): IP ties everywhere."""
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(3000, 128, seed=3)
+    ix = HipFlatIndex(128, metric)
+    ix.add(x)
+    q = np.zeros((1, 128), np.float32)
+    s, i = _check(ix, x, q, 10, metric)
+    if metric == ho.METRIC_IP:
+        assert list(i[0]) == list(range(10))
+        assert ix.stats()["fallback_queries"] >= 1     # certificate must have refused the fast path
+
+
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_duplicate_rows_tie_break_by_id(gpu, metric):
+    from hiprag import HipFlatIndex
+    base = ho.synthetic_vectors(40, 64, seed=9)
+    x = np.concatenate([base] * 60, axis=0)          # every row appears 60 times, spread over many groups
+    ix = HipFlatIndex(64, metric)
+    ix.add(x)
+    q = base[:4] + 0.01 * ho.synthetic_vectors(4, 64, seed=10)
+    _check(ix, x, q, 25, metric)
+
+
+def test_incremental_add_matches_single_add(gpu):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(1000, 96, seed=11)
+    ix = HipFlatIndex(96, "ip")
+    for lo, hi in [(0, 1), (1, 33), (33, 500), (500, 1000)]:
+        ix.add(x[lo:hi])
+    assert ix.ntotal == 1000
+    for row in (0, 31, 32, 499, 999):
+        assert np.array_equal(ix.reconstruct(row), x[row])
+    _check(ix, x, ho.synthetic_queries(5, 96), 10, ho.METRIC_IP)
+
+
+def test_id_base_offsets_ids(gpu):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(500, 64, seed=12)
+    ix = HipFlatIndex(64, "ip")
+    ix.add(x)
+    ix.set_id_base(1_000_000)
+    _check(ix, x, ho.synthetic_queries(3, 64), 5, ho.METRIC_IP, id_base=1_000_000)
+
+
+def test_save_load_roundtrip(gpu, tmp_path):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(777, 200, seed=13)
+    ix = HipFlatIndex(200, "l2")
+    ix.add(x)
+    p = str(tmp_path / "a.hipidx")
+    ix.save(p)
+    ix2 = HipFlatIndex.load(p)
+    assert ix2.ntotal == 777 and ix2.d == 200 and ix2.metric == ho.METRIC_L2
+    _check(ix2, x, ho.synthetic_queries(4, 200), 10, ho.METRIC_L2)
+
+
+def test_more_than_32_queries_and_planted_neighbours(gpu):
+    from hiprag import HipFlatIndex
+    x = ho.synthetic_vectors(8192, 1024, seed=1234)
+    rng = np.random.default_rng(77)
+    rows = rng.integers(0, 8192, size=70)
+    q = x[rows] + 0.05 * rng.standard_normal((70, 1024)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    ix = HipFlatIndex(1024, "ip")
+    ix.add(x)
+    s, i = _check(ix, x, q.astype(np.float32), 10, ho.METRIC_IP)
+    assert np.array_equal(i[:, 0], rows)
+
+
+def test_bad_arguments_raise(gpu):
+    from hiprag import HipFlatIndex, HipRagError
+    with pytest.raises(HipRagError):
+        HipFlatIndex(0, "ip")
+    with pytest.raises(HipRagError):
+        HipFlatIndex(5000, "ip")           # beyond the LDS query tile
+    ix = HipFlatIndex(8, "ip")
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((2, 9), np.float32))
+    with pytest.raises(HipRagError):
+        ix.search(np.zeros((1, 8), np.float32), 0)
+
+
+def test_device_api_and_merge_of_emulated_shards(gpu):
+    """Row-sharded search == unsharded search bit for bit, shards emulated on one GPU."""
+    import torch
+    from hiprag import HipFlatIndex, merge_topk_device
+    n, d, nq, k = 6000, 256, 12, 10
+    x = ho.synthetic_vectors(n, d, seed=21)
+    q = ho.synthetic_queries(nq, d, seed=22)
+    bounds = [0, 1501, 1502, 4000, 6000]            # ragged, not multiples of 32
+    for metric in (ho.METRIC_IP, ho.METRIC_L2):
+        parts_s, parts_i = [], []
+        qd = torch.from_numpy(q).cuda()
+        shards = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            ix = HipFlatIndex(d, metric)
+            ix.add(x[lo:hi])
+            ix.set_id_base(lo)
+            s64, s32, ids = ix.search_device(qd, k)
+            parts_s.append(s64)
+            parts_i.append(ids)
+            shards.append(ix)
+        m64, m32, mids = merge_topk_device(torch.stack(parts_s), torch.stack(parts_i), k, metric)
+        torch.cuda.synchronize()
+        full = HipFlatIndex(d, metric)
+        full.add(x)
+        fs, fi = full.search(q, k)
+        assert np.array_equal(mids.cpu().numpy(), fi)
+        assert np.array_equal(m32.cpu().numpy(), fs)          # bit for bit
+        es, ei = ho.flat_search(x, q, k, metric)
+        assert np.array_equal(fi, ei)
