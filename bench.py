@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X hybrid-retrieval hot path.
+
+Metric (BASELINE.json): queries/sec (+ p50 retrieve latency) for exact top-10 inner-product search on a
+1M x 1024-d fp32 index.  Workload = BASELINE configs[1]: "1M x 1024-d synthetic vectors, brute-force
+inner-product top-10".  A STEP is one pass of the hot path over one batch of B=32 synthetic queries already
+resident in HBM: scan (fp32 MFMA, HBM-bound) -> group select -> fp64 re-score + certificate -> (N>1: one RCCL
+all-gather of the packed partial top-k + canonical merge).
+
+Multi-GPU (driver launches one rank per GPU through torch.distributed.run): the 1M rows are sharded row-wise
+across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; one step is kept
+in flight so the exchange of step i overlaps the scan of step i+1.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel = scan_kernel; achieved = algorithmic bytes per launch (rows_local * d_pad * 4,
+               DESIGN.md) / mean launch duration from HIP events recorded on the launch stream around every scan
+               launch of the timed region; peak 8000 GB/s (MI355X_MICROARCH.md).
+  cpu_baseline the oracle's reference-faithful fp32 twin (one query per call, one thread) timed on this box's host
+               cores on a bounded sample, rank 0, N=1 only.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "intool-rag_amd"))
+
+N_ROWS = 1_000_000
+DIM = 1024
+TOPK = 10
+BATCH = 32
+N_QUERIES = 4096
+CHUNK = 31250                 # generation unit: N_ROWS/32, so shards of 1,2,4,8,16,32 ranks align to chunks
+HBM_PEAK_GBS = 8000.0
+
+
+def gen_chunk(torch, chunk_id: int, rows: int, dev):
+    """Unit-norm Gaussian rows; content depends only on the chunk id, never on the sharding."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + chunk_id)
+    x = torch.randn((rows, DIM), generator=g, device=dev, dtype=torch.float32)
+    x /= x.norm(dim=1, keepdim=True)
+    return x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hiprag import HipFlatIndex
+    from hiprag.sharded import ShardedFlatIndex
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    n_rows = args.rows
+    chunk = CHUNK if n_rows == N_ROWS else max(1, n_rows // 32)
+
+    # ---- build the local shard (rows resident in HBM before anything is timed) ----------------------
+    n_chunks = (n_rows + chunk - 1) // chunk
+    my_chunks = [c for c in range(n_chunks) if (c * world) // n_chunks == rank] if world > 1 else list(range(n_chunks))
+    row_lo = my_chunks[0] * chunk if my_chunks else 0
+    index = HipFlatIndex(DIM, "ip", device=local_rank)
+    keep_host = (world == 1 and not args.no_cpu_baseline)
+    host_rows = []
+    t0 = time.time()
+    for c in my_chunks:
+        rows = min(chunk, n_rows - c * chunk)
+        x = gen_chunk(torch, c, rows, dev)
+        index.add_device(x)
+        if keep_host:
+            host_rows.append(x.cpu().numpy())
+        del x
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    sharded = ShardedFlatIndex(index, row_lo)
+    index.reserve_search(TOPK)
+
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
+    queries /= queries.norm(dim=1, keepdim=True)
+    nb = N_QUERIES // BATCH
+
+    def run_steps(n, first):
+        """n pipelined steps; the all-gather of step i is in flight while step i+1 scans."""
+        ticket, last = None, None
+        for s in range(n):
+            b = (first + s) % nb
+            t = sharded.search_begin(queries[b * BATCH:(b + 1) * BATCH], TOPK)
+            if ticket is not None:
+                last = sharded.search_end(ticket)
+            ticket = t
+        if ticket is not None:
+            last = sharded.search_end(ticket)
+        return last
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup, 0)
+    barrier()
+    index.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    last = run_steps(args.steps, args.warmup)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = index.stats()
+    index.enable_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        scan = torch.tensor([st["avg_scan_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(scan, op=dist.ReduceOp.MAX)
+        scan_ms = float(scan.item())
+    else:
+        scan_ms = float(st["avg_scan_ms"])
+
+    # ---- p50 latency of single queries through the host boundary (python -> C-ABI -> sync) -----------
+    lat = []
+    for i in range(120):
+        qi = queries[i:i + 1]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sharded.search_device(qi, TOPK)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat = np.sort(np.asarray(lat[20:]))
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    qps = args.steps * BATCH / elapsed
+    bytes_per_launch = int(st["bytes_per_pass"])           # local rows * d_pad * 4: what ONE scan launch streams
+    achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    out = {
+        "metric": "queries/sec, exact top-10 inner-product search, 1M x 1024-d fp32 index",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
+                   "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH,
+                   "sharding": f"rows/{world}" if world > 1 else "none",
+                   "exchange": "1 all-gather of [2,32,10] int64 per step, 1 step in flight" if world > 1 else "none"},
+        "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
+        "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
+        "fallback_queries": int(st["fallback_queries"]),
+        "build_s": round(build_s, 2),
+        "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
+                     "launches_timed": int(st["timed_passes"])},
+    }
+
+    # ---- CPU baseline: the oracle's reference-faithful twin, bounded sample, rank 0, N=1 only ----------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import hybrid_oracle as ho
+        xh = np.concatenate(host_rows, axis=0)
+        del host_rows
+        nsample = 24
+        qh = queries[:nsample].cpu().numpy()
+        ho.flat_search_f32_faithful(xh[:20000], qh[:2], TOPK, ho.METRIC_IP)   # warm the pages / code
+        t1 = time.perf_counter()
+        cs, ci = ho.flat_search_f32_faithful(xh, qh, TOPK, ho.METRIC_IP)
+        cpu_s = time.perf_counter() - t1
+        g64, g32, gi = index.search_device(queries[:nsample], TOPK)
+        torch.cuda.synchronize()
+        agree = bool(np.array_equal(gi.cpu().numpy(), ci))
+        out["cpu_baseline"] = {"value": round(nsample / cpu_s, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"{nsample} queries x full {n_rows}x{DIM} index, one query per call, 1 thread, "
+                                         f"fp32 C restatement of IndexFlat search (FAISS itself is not installed)",
+                               "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+                               "ids_equal_gpu": agree}
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

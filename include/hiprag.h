@@ -86,17 +86,20 @@ typedef struct hipidx_stats {
     int64_t queries;           /* queries answered */
     int64_t fallback_queries;  /* queries whose fast-path certificate failed and took the exhaustive path */
     int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
-    float last_scan_ms;        /* HIP-event time of the last scan kernel if timing was enabled, else -1 */
+    int64_t timed_passes;      /* scan launches averaged into avg_scan_ms (at most the last 512) */
+    float avg_scan_ms;         /* mean HIP-event duration of the scan kernel since timing was enabled, else -1 */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
-int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* records events around the scan kernel; get_stats syncs */
+int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* HIP events around each scan launch, on its stream; get_stats syncs */
 
 /* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
- * in_scores64 / in_ids: [n_parts, nq, k_in] (device).  Canonical comparator as above; ids < 0 are padding.
+ * in_scores64 / in_ids: n_parts blocks of [nq, k_in] (device), block p starting part_stride ELEMENTS after block
+ * p-1 (0 = dense, nq*k_in) so both arrays can live interleaved in one all-gathered buffer.  Canonical comparator
+ * as above; ids < 0 are padding.
  * New capability (the reference is single-process); correctness criterion: sharded == unsharded, bit for bit. */
 int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_ids_dev, int32_t n_parts, int32_t nq,
-                              int32_t k_in, int32_t k_out, int32_t metric, double* out_scores64_dev,
-                              float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+                              int32_t k_in, int32_t k_out, int64_t part_stride, int32_t metric,
+                              double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
 /* ---- BM25 term-at-a-time sparse scoring (named by the reference's README.md:54-58 and rag/config.py:43-45,
  *      implemented nowhere in it; spec in DESIGN.md) -------------------------------------------------------

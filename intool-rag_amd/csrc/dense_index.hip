@@ -42,7 +42,7 @@ constexpr int kPieceVec4 = 64;
 constexpr int kMaxQ = 32;          // queries per pass
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
-constexpr int kRing = 16;          // pieces in flight per wave (16 KiB)
+constexpr int kSelPerWave = 8192;  // group maxima filtered by one wave of select_wave_kernel
 constexpr int kExRows = 4096;      // rows per workgroup in the exhaustive path
 constexpr int kMaxK = 1000;
 constexpr int kSlackGroups = 6;
@@ -121,9 +121,29 @@ __global__ void norms_kernel(const float* __restrict__ src, int64_t row0, int64_
 // ------------------------------------------------------------------------------------------------------
 // K1: the scan
 // ------------------------------------------------------------------------------------------------------
+// Query fragments: Qf[p][lane = h*32 + b] = Q[b][8p + 4h + 0..3] (zero for b >= nq or columns >= d) -- the LDS image
+// of the scan's B operand, written once per pass so every workgroup's prologue is one coalesced 16-B-per-lane copy.
+__global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q, int nq, int d, int P, float4* __restrict__ qf)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * kPieceVec4) return;
+    const int p = idx >> 6, l = idx & 63;
+    const int b = l & 31, h = l >> 5;
+    const int col = 8 * p + 4 * h;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < nq) {
+        const float* s = q + (int64_t)b * d + col;
+        if (col + 0 < d) v.x = s[0];
+        if (col + 1 < d) v.y = s[1];
+        if (col + 2 < d) v.z = s[2];
+        if (col + 3 < d) v.w = s[3];
+    }
+    qf[idx] = v;
+}
+
 struct ScanArgs {
     const float4* xb;     // blocked index
-    const float* q;       // [nq, d] row-major
+    const float4* qf;     // [P*64] query fragments (qprep_kernel)
     const float* norms;   // [rows] squared norms (L2 only)
     float* gmax;          // [kMaxQ, gstride] group maxima
     int64_t gstride;
@@ -132,7 +152,7 @@ struct ScanArgs {
     int nq, d, P;
 };
 
-template <int METRIC, int NWAVES>
+template <int METRIC, int NWAVES, int VARIANT, int RING = 16>
 __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P][64] query fragments: lane = h*32 + b holds Q[b][8p + 4h + 0..3]
@@ -142,28 +162,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> block ranges live in SGPRs
     const int P = a.P;
 
-    for (int idx = tid; idx < P * kPieceVec4; idx += NT) {
-        const int p = idx >> 6, l = idx & 63;
-        const int b = l & 31, h = l >> 5;
-        const int col = 8 * p + 4 * h;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < a.nq) {
-            const float* s = a.q + (int64_t)b * a.d + col;
-            if (col + 0 < a.d) v.x = s[0];
-            if (col + 1 < a.d) v.y = s[1];
-            if (col + 2 < a.d) v.z = s[2];
-            if (col + 3 < a.d) v.w = s[3];
-        }
-        qs[idx] = v;
-    }
-    __syncthreads();
-
-    // contiguous block range of this wave
+    // contiguous block range of this wave: equal shares of ceil(nblocks / W) blocks, so every active wave ends at the
+    // same time (a ragged last round would leave a quarter of the waves streaming alone at latency-bound rates)
     const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave;
     const int64_t W = (int64_t)gridDim.x * NWAVES;
-    const int64_t b0 = gw * a.nblocks / W;
-    const int64_t b1 = (gw + 1) * a.nblocks / W;
-    if (b1 <= b0) return;
+    const int64_t bpw = (a.nblocks + W - 1) / W;
+    const int64_t b0 = min(gw * bpw, a.nblocks);
+    const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);  // pieces in this wave's stream
     const float4* base = a.xb + b0 * P * kPieceVec4;  // wave-uniform; lanes add 16 B each through the VGPR offset
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -171,14 +176,21 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
 
     // The X stream is driven by hand: loads are inline asm (invisible to hipcc's waitcnt pass, which otherwise drains
     // the queue with vmcnt(0) at the loop back-edge) and every use is fenced by a counted s_waitcnt that takes the
-    // ring slot as an in/out operand, so no consumer can be scheduled above its wait.  vmcnt(kRing-1) before slot i is
+    // ring slot as an in/out operand, so no consumer can be scheduled above its wait.  vmcnt(RING-1) before slot i is
     // exact when only the ring is in flight and merely conservative when the epilogue's store / norm loads are queued too.
-    f32x4 ring[kRing];
+    // The ring is armed BEFORE the query tile is staged, so HBM is streaming while the prologue runs.
+    f32x4 ring[RING];
+    if (S > 0) {
 #pragma unroll
-    for (int i = 0; i < kRing; ++i) {
-        const unsigned voff = lane16 + (unsigned)min(i, S - 1) * 1024u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+        for (int i = 0; i < RING; ++i) {
+            const unsigned voff = lane16 + (unsigned)min(i, S - 1) * 1024u;
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+        }
     }
+
+    for (int idx = tid; idx < P * kPieceVec4; idx += NT) qs[idx] = a.qf[idx];
+    __syncthreads();
+    if (S <= 0) return;
 
     int s = 0;
     float4 bnext = qs[lane];
@@ -194,31 +206,36 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        for (int pp = 0; pp < P; pp += kRing) {
+        for (int pp = 0; pp < P; pp += RING) {
 #pragma unroll
-            for (int i = 0; i < kRing; ++i) {
-                // one step = one 1 KiB piece: 4 MFMAs on the piece loaded kRing steps ago, then re-arm its ring slot
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[i]) : "n"(kRing - 1) : "memory");
+            for (int i = 0; i < RING; ++i) {
+                // one step = one 1 KiB piece: 4 MFMAs on the piece loaded RING steps ago, then re-arm its ring slot
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[i]) : "n"(RING - 1) : "memory");
                 const f32x4 av = ring[i];
                 const float4 bv = bnext;
                 int nx = pp + i + 1;
                 nx = nx == P ? 0 : nx;
                 bnext = qs[nx * kPieceVec4 + lane];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
-                const unsigned voff = lane16 + (unsigned)min(s + kRing + i, S - 1) * 1024u;
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+                if (VARIANT != 6 && VARIANT != 7) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
+                else asm volatile("" ::"v"(av[0]));
+                if (VARIANT != 1 && VARIANT != 6 && VARIANT != 7) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
+                } else {
+                    asm volatile("" ::"v"(av[1]), "v"(av[2]), "v"(av[3]));
+                }
+                const unsigned voff = lane16 + (unsigned)min(s + RING + i, S - 1) * 1024u;
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            s += kRing;
+            s += RING;
         }
         // epilogue: acc[4g + j] = <x_row, q_qb>, row = 32*blk + 8g + 4h + j
         float sc[16];
         if (METRIC == HIPRAG_METRIC_L2) {
-            // the 4 norm loads were issued before this block's P >= kRing ring re-arms: all but the kRing youngest done
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(kRing) : "memory");
+            // the 4 norm loads were issued before this block's P >= RING ring re-arms: all but the RING youngest done
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sc[4 * g + 0] = 2.f * acc[4 * g + 0] - nrm[g][0];
@@ -409,6 +426,109 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K2b (fast form, K' + 1 <= 64, i.e. k <= 57): the same stages as finish_kernel, but every selection runs on the
+// wave-resident sorted list of topk_device.h instead of barrier-per-round argmax: wave 0 merges the per-wave
+// winners of select_wave_kernel, all four waves re-score the K' groups in fp64, wave 0 picks the final top-k.
+// ------------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(kSelThreads) void finish_wave_kernel(FinishArgs a)
+{
+    extern __shared__ unsigned char smem[];
+    u64* selk = reinterpret_cast<u64*>(smem);            // [64] packed winners (group maxima)
+    u64* candk = selk + 64;                              // [256] fp64 keys of re-scored rows
+    i64* candi = reinterpret_cast<i64*>(candk + 256);    // [256] row ids
+    double* dred = reinterpret_cast<double*>(candi + 256);
+    float* qv = reinterpret_cast<float*>(dred + kSelThreads / 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;
+    const int dpad = a.P * 8;
+    const int K1 = a.Kp + 1;
+
+    double qpart = 0.0;
+    for (int c = tid; c < dpad; c += kSelThreads) {
+        float v = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+        qv[c] = v;
+        qpart += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
+    if (lane == 0) dred[wave] = qpart;
+
+    if (wave == 0) {
+        const u64* sk = a.ck + (int64_t)q * a.ncand;
+        const i64* si = a.ci + (int64_t)q * a.ncand;
+        WaveListPacked L;
+        L.init();
+        u64 tau = 0;
+        for (int64_t base = 0; base < a.ncand; base += 64) {
+            const int64_t i = base + lane;
+            u64 c = 0;
+            if (i < a.ncand) {
+                const u64 kk = sk[i];
+                if (kk != 0) c = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
+            }
+            tau = L.offer(c, K1, tau);
+        }
+        selk[lane] = L.e;
+    }
+    __syncthreads();
+    double qn2 = 0.0;
+    for (int w = 0; w < kSelThreads / 64; ++w) qn2 += dred[w];
+
+    for (int j = wave; j < 64; j += kSelThreads / 64) {   // 64 slots x 4 rows = the 256 candidate entries
+        u64 key = 0;
+        i64 row = -1;
+        if (j < a.Kp) {
+            const u64 e = selk[j];
+            if (e != 0) {
+                const i64 gi = (i64)packed_index(e);
+                const int64_t blk = gi >> 3;
+                const int r0 = 8 * (int)(gi & 3) + 4 * (int)((gi >> 2) & 1);
+                const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+                row = blk * kRowsPerBlock + r0 + (lane & 3);
+                if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+            }
+        }
+        if (lane < 4) { candk[j * 4 + lane] = key; candi[j * 4 + lane] = row; }
+    }
+    __syncthreads();
+
+    if (wave == 0) {
+        WaveListPair F;
+        F.init();
+#pragma unroll
+        for (int base = 0; base < 256; base += 64) F.offer(candk[base + lane], candi[base + lane], a.k);
+        if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
+        const u64 kth_key = readlane_u64(F.k, a.k - 1);
+        if (lane == 0) {
+            int flag = 0;
+            const u64 bk = selk[a.Kp];  // best group NOT re-scored
+            if (bk != 0) {
+                const float m = packed_value(bk);
+                if (m != -INFINITY) {
+                    const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
+                    const double qn = sqrt(qn2);
+                    const double u = 5.9604644775390625e-08;  // 2^-24
+                    double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
+                    double kth_sel;
+                    if (METRIC == HIPRAG_METRIC_IP) {
+                        kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
+                    } else {
+                        eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
+                        kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
+                        eps += 4.0 * u * qn2;
+                    }
+                    if (!(kth_sel > (double)m + eps)) flag = 1;
+                }
+            }
+            a.flags[q] = flag;
+            if (flag) atomicAdd(a.fallback_counter, 1ull);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K2c / K2d: exhaustive exact path for flagged queries (exit immediately otherwise)
 // ------------------------------------------------------------------------------------------------------
 struct ExArgs {
@@ -421,14 +541,12 @@ struct ExArgs {
     float* out32;
     int64_t* out_ids;
     int64_t ntotal, id_base;
-    int d, P, k, kk, nslices;
+    int d, P, k, kk, nslices, nq;
 };
 
 template <int METRIC>
 __global__ __launch_bounds__(kSelThreads) void exhaustive_scan_kernel(ExArgs a)
 {
-    const int q = blockIdx.y;
-    if (!a.flags[q]) return;
     extern __shared__ unsigned char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
@@ -436,24 +554,28 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_scan_kernel(ExArgs a)
     float* qv = reinterpret_cast<float*>(red + 2 * (kSelThreads / 64));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dpad = a.P * 8;
-    for (int c = tid; c < dpad; c += kSelThreads) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
-    __syncthreads();
     const int64_t row_base = (int64_t)blockIdx.x * kExRows;
     const int nrows = (int)min((int64_t)kExRows, a.ntotal - row_base);
-    for (int g = wave; g * 4 < kExRows; g += kSelThreads / 64) {
-        const int64_t row0 = row_base + (int64_t)g * 4;
-        u64 key = 0;
-        const int64_t row = row0 + (lane & 3);
-        if (row0 < a.ntotal) {
-            const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
-            if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+    for (int q = 0; q < a.nq; ++q) {
+        if (!a.flags[q]) continue;  // uniform across the workgroup; the common case touches nothing else
+        __syncthreads();
+        for (int c = tid; c < dpad; c += kSelThreads) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+        __syncthreads();
+        for (int g = wave; g * 4 < kExRows; g += kSelThreads / 64) {
+            const int64_t row0 = row_base + (int64_t)g * 4;
+            u64 key = 0;
+            const int64_t row = row0 + (lane & 3);
+            if (row0 < a.ntotal) {
+                const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
+                if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+            }
+            if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
         }
-        if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
+        __syncthreads();
+        u64* ok = a.ek + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
+        i64* oi = a.ei + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
+        wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
     }
-    __syncthreads();
-    u64* ok = a.ek + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
-    i64* oi = a.ei + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
-    wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
 }
 
 template <int METRIC>
@@ -486,14 +608,16 @@ struct DenseIndex {
     int n_cu = 256;
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    DevBuf gmax, ck, ci, flags, ek, ei, qbuf, o64, o32, oid;
+    DevBuf gmax, qf, ck, ci, flags, ek, ei, qbuf, o64, o32, oid;
     int ws_k = 0;
     int64_t ws_blocks = 0;
     // stats
     int64_t passes = 0, queries = 0;
+    // timing: a ring of event pairs around the scan kernel, averaged by get_stats (no sync inside the search path)
+    static constexpr int kEvRing = 512;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    std::vector<hipEvent_t> evs;   // 2*kEvRing once timing was enabled
+    int64_t ev_count = 0;          // pairs recorded since timing was (re)enabled
 
     int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
     unsigned* max_norm2_bits() { return scalars.as<unsigned>(); }
@@ -501,8 +625,7 @@ struct DenseIndex {
 
     ~DenseIndex()
     {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
 
     int32_t init()
@@ -594,8 +717,10 @@ struct DenseIndex {
         const int ekk = std::min(kk, kExRows);
         int32_t rc;
         if ((rc = gmax.reserve((size_t)kMaxQ * gstride * sizeof(float)))) return rc;
-        if ((rc = ck.reserve((size_t)kMaxQ * nchunks * K1 * sizeof(u64)))) return rc;
-        if ((rc = ci.reserve((size_t)kMaxQ * nchunks * K1 * sizeof(i64)))) return rc;
+        if ((rc = qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
+        const int64_t nlists = std::max(nchunks, ((gstride + kSelPerWave - 1) / kSelPerWave + 3) / 4 * 4);
+        if ((rc = ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
+        if ((rc = ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
         if ((rc = flags.reserve(kMaxQ * sizeof(int)))) return rc;
         if ((rc = ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
@@ -614,42 +739,64 @@ struct DenseIndex {
         const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
 
         ScanArgs sa;
-        sa.xb = xb.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = gmax.as<float>();
+        sa.xb = xb.as<float4>(); sa.qf = qf.as<float4>(); sa.norms = norms.as<float>(); sa.gmax = gmax.as<float>();
         sa.gstride = gstride; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
-        constexpr int NW = 8;
-        auto scan = scan_kernel<METRIC, NW>;
+        const char* vs = getenv("HIPRAG_SCAN_VARIANT");  // timing experiments only (variants 1 and 6 give wrong scores)
+        const int variant = vs ? atoi(vs) : 0;
+        int NW = 8;
+        void (*scan)(ScanArgs) = scan_kernel<METRIC, 8, 0>;
+        if (variant == 1) scan = scan_kernel<METRIC, 8, 1>;
+        if (variant == 2) { scan = scan_kernel<METRIC, 16, 0>; NW = 16; }
+        if (variant == 6) scan = scan_kernel<METRIC, 8, 6>;
+        if (variant == 8) scan = scan_kernel<METRIC, 8, 0, 32>;
+        if (variant == 11) { scan = scan_kernel<METRIC, 4, 0, 32>; NW = 4; }
         const size_t scan_lds = (size_t)P * 1024;
         HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)scan_lds));
-        if (timing) HR_CHECK_HIP(hipEventRecord(ev0, st));
+        hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
+                           qf.as<float4>());
+        const int slot = (int)(ev_count % kEvRing);
+        if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * slot], st));
         if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
-        if (timing) { HR_CHECK_HIP(hipEventRecord(ev1, st)); ev_valid = true; }
-
-        hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
-                           (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, ck.as<u64>(), ci.as<i64>());
+        if (timing) { HR_CHECK_HIP(hipEventRecord(evs[2 * slot + 1], st)); ++ev_count; }
 
         FinishArgs fa;
         fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = ck.as<u64>(); fa.ci = ci.as<i64>();
         fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
         fa.flags = flags.as<int>(); fa.fallback_counter = fallback_counter();
-        fa.ntotal = ntotal; fa.id_base = id_base; fa.ncand = nchunks * K1; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp;
-        const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
-                               (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
-        auto fin = finish_kernel<METRIC>;
-        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)fin_lds));
-        hipLaunchKernelGGL(fin, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
+        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp;
+        if (K1 <= 64) {
+            // fast selectors: one wave filters kSelPerWave group maxima against its running K1-th best
+            const int64_t nwaves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
+            const int64_t nslices = (nwaves + 3) / 4;
+            hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)nslices, nq), dim3(256), 0, st,
+                               (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, kSelPerWave, K1, ck.as<u64>(),
+                               ci.as<i64>());
+            fa.ncand = nslices * 4 * K1;
+            const size_t fin_lds = 64 * 8 + 256 * 16 + (kSelThreads / 64) * sizeof(double) + (size_t)P * 8 * sizeof(float);
+            hipLaunchKernelGGL(finish_wave_kernel<METRIC>, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
+        } else {
+            hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
+                               (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, ck.as<u64>(), ci.as<i64>());
+            fa.ncand = nchunks * K1;
+            const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
+                                   (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
+            auto fin = finish_kernel<METRIC>;
+            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)fin_lds));
+            hipLaunchKernelGGL(fin, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
+        }
 
         ExArgs ea;
         ea.xb = xb.as<float4>(); ea.q = q_dev; ea.flags = flags.as<int>(); ea.ek = ek.as<u64>(); ea.ei = ei.as<i64>();
         ea.out64 = o64p; ea.out32 = o32p; ea.out_ids = oidp; ea.ntotal = ntotal; ea.id_base = id_base;
-        ea.d = d; ea.P = P; ea.k = k; ea.kk = std::min(k, kExRows);
+        ea.d = d; ea.P = P; ea.k = k; ea.kk = std::min(k, kExRows); ea.nq = nq;
         ea.nslices = (int)std::max<int64_t>(1, (ntotal + kExRows - 1) / kExRows);
         const size_t ex_lds = (size_t)kSelChunk * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) + (size_t)P * 8 * sizeof(float);
         auto exs = exhaustive_scan_kernel<METRIC>;
         HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exs), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)ex_lds));
-        hipLaunchKernelGGL(exs, dim3(ea.nslices, nq), dim3(kSelThreads), ex_lds, st, ea);
+        hipLaunchKernelGGL(exs, dim3(ea.nslices), dim3(kSelThreads), ex_lds, st, ea);
         const size_t em_lds = (size_t)kSelChunk * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId);
         auto exm = exhaustive_merge_kernel<METRIC>;
         HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exm), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -665,9 +812,9 @@ struct DenseIndex {
     {
         int32_t rc = reserve_search(k);
         if (rc) return rc;
-        if (timing && !ev0) {
-            HR_CHECK_HIP(hipEventCreate(&ev0));
-            HR_CHECK_HIP(hipEventCreate(&ev1));
+        if (timing && evs.empty()) {
+            evs.resize(2 * kEvRing);
+            for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
         }
         for (int o = 0; o < nq; o += kMaxQ) {
             const int m = std::min(kMaxQ, nq - o);
@@ -911,7 +1058,7 @@ int32_t hipidx_enable_timing(uint64_t h, int32_t on)
 {
     GET_INDEX(h);
     ix->timing = on != 0;
-    ix->ev_valid = false;
+    ix->ev_count = 0;
     return HIPRAG_OK;
 }
 
@@ -927,10 +1074,17 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
     out->fallback_queries = (int64_t)fb;
     out->bytes_per_pass = ix->nblocks() * ix->P * 1024 +
                           (ix->metric == HIPRAG_METRIC_L2 ? ix->nblocks() * kRowsPerBlock * 4 : 0);
-    out->last_scan_ms = -1.f;
-    if (ix->timing && ix->ev_valid) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) == hipSuccess) out->last_scan_ms = ms;
+    out->avg_scan_ms = -1.f;
+    out->timed_passes = 0;
+    if (!ix->evs.empty() && ix->ev_count > 0) {
+        const int64_t n = std::min<int64_t>(ix->ev_count, DenseIndex::kEvRing);
+        double sum = 0.0;
+        int64_t ok = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ix->evs[2 * i], ix->evs[2 * i + 1]) == hipSuccess) { sum += ms; ++ok; }
+        }
+        if (ok) { out->avg_scan_ms = (float)(sum / ok); out->timed_passes = ok; }
     }
     return HIPRAG_OK;
 }

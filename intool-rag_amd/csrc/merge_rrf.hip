@@ -16,7 +16,7 @@ constexpr int kThreads = 256;
 
 template <int METRIC>
 __global__ __launch_bounds__(kThreads) void merge_topk_kernel(const double* __restrict__ in_s, const i64* __restrict__ in_i,
-                                                             int n_parts, int nq, int k_in, int k_out,
+                                                             int n_parts, int nq, int k_in, int k_out, i64 part_stride,
                                                              double* __restrict__ out64, float* __restrict__ out32,
                                                              i64* __restrict__ out_ids)
 {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kThreads) void merge_topk_kernel(const double* __re
     const i64 M = (i64)n_parts * k_in;
     auto load = [&](i64 i, u64& k, i64& id) {
         const int part = (int)(i / k_in), j = (int)(i % k_in);
-        const i64 o = ((i64)part * nq + q) * k_in + j;
+        const i64 o = (i64)part * part_stride + (i64)q * k_in + j;
         id = in_i[o];
         const double s = in_s[o];
         k = id < 0 ? 0ull : ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
@@ -119,9 +119,11 @@ using namespace hiprag;
 extern "C" {
 
 int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_ids_dev, int32_t n_parts, int32_t nq,
-                              int32_t k_in, int32_t k_out, int32_t metric, double* out_scores64_dev,
-                              float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+                              int32_t k_in, int32_t k_out, int64_t part_stride, int32_t metric,
+                              double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
 {
+    if (part_stride == 0) part_stride = (int64_t)nq * k_in;
+    HR_REQUIRE(part_stride >= (int64_t)nq * k_in, "part_stride smaller than one part");
     HR_REQUIRE(n_parts > 0 && nq >= 0 && k_in > 0 && k_out > 0 && k_out < kTile, "bad merge shape");
     HR_REQUIRE(metric == HIPRAG_METRIC_IP || metric == HIPRAG_METRIC_L2, "unknown metric %d", metric);
     if (nq == 0) return HIPRAG_OK;
@@ -130,7 +132,7 @@ int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_i
     auto kern = metric == HIPRAG_METRIC_IP ? merge_topk_kernel<HIPRAG_METRIC_IP> : merge_topk_kernel<HIPRAG_METRIC_L2>;
     HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(nq), dim3(kThreads), lds, (hipStream_t)stream, in_scores64_dev,
-                       (const i64*)in_ids_dev, n_parts, nq, k_in, k_out, out_scores64_dev, out_scores_dev,
+                       (const i64*)in_ids_dev, n_parts, nq, k_in, k_out, (i64)part_stride, out_scores64_dev, out_scores_dev,
                        (i64*)out_ids_dev);
     HR_CHECK_HIP(hipGetLastError());
     return HIPRAG_OK;

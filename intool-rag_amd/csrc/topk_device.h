@@ -171,4 +171,130 @@ __global__ __launch_bounds__(256) void select_f32_kernel(const float* __restrict
     wg_topk_rounds<256>(keys, ids, n, K1, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wave-resident sorted list ("filter and insert"): exact top-K for K <= 64 with one compare per rejected element.
+// Lane j of the wave holds the j-th best entry seen so far; a candidate that beats the current K-th entry is
+// inserted by one wave-wide compare + a shift by one lane.  After warm-up almost every element of a stream fails
+// the threshold test, so a wave filters a stream at close to load speed.
+//
+// Two entry flavours share the code:
+//   packed  : u64 = (ord32(value) << 32) | (0xFFFFFFFF - index32): one integer compare orders (value desc, index asc)
+//   pair    : (u64 key, i64 id) with the canonical comparator (fp64 scores, 64-bit ids)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 pack_key(float v, u32 idx) { return ((u64)ord32(v) << 32) | (u64)(0xFFFFFFFFu - idx); }
+__device__ __forceinline__ u32 packed_index(u64 k) { return 0xFFFFFFFFu - (u32)(k & 0xFFFFFFFFull); }
+__device__ __forceinline__ float packed_value(u64 k) { return unord32((u32)(k >> 32)); }
+
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane)
+{
+    const u32 lo = __builtin_amdgcn_readlane((int)(u32)v, lane);
+    const u32 hi = __builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+
+struct WaveListPacked {
+    u64 e;  // this lane's entry (0 = empty)
+    __device__ __forceinline__ void init() { e = 0; }
+    // insert a wave-uniform candidate c (c != 0); keeps lanes sorted descending
+    __device__ __forceinline__ void insert(u64 c)
+    {
+        const int lane = threadIdx.x & 63;
+        const u64 up = __shfl_up(e, 1);
+        const bool before = c > e;
+        const bool before_prev = lane > 0 && c > up;
+        if (before) e = before_prev ? up : c;
+    }
+    __device__ __forceinline__ u64 kth(int K) const { return readlane_u64(e, K - 1); }
+    // Offer every lane's candidate (0 = nothing) against threshold tau (the current K-th entry); returns the new tau.
+    __device__ __forceinline__ u64 offer(u64 c, int K, u64 tau)
+    {
+        unsigned long long mask = __ballot(c > tau);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const u64 cj = readlane_u64(c, j);
+            if (cj > tau) {  // wave-uniform
+                insert(cj);
+                tau = kth(K);
+            }
+        }
+        return tau;
+    }
+};
+
+struct WaveListPair {
+    u64 k;
+    i64 id;
+    __device__ __forceinline__ void init() { k = 0; id = 0x7FFFFFFFFFFFFFFFll; }
+    __device__ __forceinline__ void insert(u64 ck, i64 cid)
+    {
+        const int lane = threadIdx.x & 63;
+        const u64 upk = __shfl_up(k, 1);
+        const i64 upi = __shfl_up(id, 1);
+        const bool before = key_before(ck, cid, k, id);
+        const bool before_prev = lane > 0 && key_before(ck, cid, upk, upi);
+        if (before) {
+            k = before_prev ? upk : ck;
+            id = before_prev ? upi : cid;
+        }
+    }
+    // Offer every lane's candidate (key 0 = nothing); K-th entry is the threshold.
+    __device__ __forceinline__ void offer(u64 ck, i64 cid, int K)
+    {
+        u64 tk = readlane_u64(k, K - 1);
+        i64 ti = (i64)readlane_u64((u64)id, K - 1);
+        unsigned long long mask = __ballot(ck != 0 && key_before(ck, cid, tk, ti));
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const u64 cj = readlane_u64(ck, j);
+            const i64 ij = (i64)readlane_u64((u64)cid, j);
+            if (key_before(cj, ij, tk, ti)) {
+                insert(cj, ij);
+                tk = readlane_u64(k, K - 1);
+                ti = (i64)readlane_u64((u64)id, K - 1);
+            }
+        }
+    }
+};
+
+// Level-1 selector, K1 <= 64: grid (nslices, nq), 256 threads = 4 independent waves; wave w of slice s filters the
+// contiguous elements [ (4s+w)*per_wave, +per_wave ) of query q's float array and writes its sorted top-K1 as
+// (key = ord32(v) << 32, id = index) to ck/ci[q][(4s+w)*K1 ..].  POSITIVE_ONLY drops v <= 0.
+template <bool POSITIVE_ONLY>
+__global__ __launch_bounds__(256) void select_wave_kernel(const float* __restrict__ vals, i64 stride, i64 n_total,
+                                                         int per_wave, int K1, u64* __restrict__ ck, i64* __restrict__ ci)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.y;
+    const i64 wave = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * 4;
+    const i64 lo = wave * per_wave;
+    i64 hi = lo + per_wave;
+    if (hi > n_total) hi = n_total;
+    const float* src = vals + (i64)q * stride;
+    WaveListPacked L;
+    L.init();
+    u64 tau = 0;
+    for (i64 base = lo; base < hi; base += 256) {
+        u64 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const i64 i = base + u * 64 + lane;
+            c[u] = 0;
+            if (i < hi) {
+                const float v = src[i];
+                if (!POSITIVE_ONLY || v > 0.f) c[u] = pack_key(v, (u32)i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tau = L.offer(c[u], K1, tau);
+    }
+    if (lane < K1) {
+        const i64 o = ((i64)q * nwaves + wave) * K1 + lane;
+        ck[o] = L.e & 0xFFFFFFFF00000000ull;
+        ci[o] = L.e ? (i64)packed_index(L.e) : -1;
+    }
+}
+
 }  // namespace hiprag

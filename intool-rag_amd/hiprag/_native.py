@@ -25,7 +25,7 @@ class HipRagError(RuntimeError):
 
 class HipIdxStats(ctypes.Structure):
     _fields_ = [("passes", c_int64), ("queries", c_int64), ("fallback_queries", c_int64),
-                ("bytes_per_pass", c_int64), ("last_scan_ms", c_float)]
+                ("bytes_per_pass", c_int64), ("timed_passes", c_int64), ("avg_scan_ms", c_float)]
 
 
 class HipBm25Stats(ctypes.Structure):
@@ -59,8 +59,8 @@ SIGNATURES = {
     "hipidx_load": [c_char_p, c_int32, u64p],
     "hipidx_get_stats": [c_uint64, POINTER(HipIdxStats)],
     "hipidx_enable_timing": [c_uint64, c_int32],
-    "hiprag_merge_topk_dev": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
-                              c_void_p, c_void_p],
+    "hiprag_merge_topk_dev": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p,
+                              c_void_p, c_void_p, c_void_p],
     "hipbm25_create": [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, u64p],
     "hipbm25_destroy": [c_uint64],
     "hipbm25_set_id_base": [c_uint64, c_int64],

@@ -144,16 +144,25 @@ def _stream_ptr():
 
 
 def merge_topk_device(scores64, ids, k_out: int, metric, out=None):
-    """Merge [n_parts, nq, k_in] partial lists (CUDA tensors) -> (scores64, scores32, ids) [nq,k_out]."""
+    """Merge [n_parts, nq, k_in] partial lists (CUDA tensors) -> (scores64, scores32, ids) [nq,k_out].
+
+    The two inputs may be strided views along dim 0 (e.g. halves of one all-gathered [G,2,nq,k] buffer) as long
+    as each [nq,k_in] part is contiguous and both use the same part stride."""
     import torch
     n_parts, nq, k_in = scores64.shape
+    for t in (scores64, ids):
+        if t.stride(2) != 1 or t.stride(1) != k_in:
+            raise ValueError("each [nq,k_in] part must be contiguous")
+    part_stride = scores64.stride(0) if n_parts > 1 else nq * k_in
+    if n_parts > 1 and ids.stride(0) != part_stride:
+        raise ValueError("scores and ids must use the same part stride")
     dev = scores64.device
     if out is None:
         out = (torch.empty((nq, k_out), dtype=torch.float64, device=dev),
                torch.empty((nq, k_out), dtype=torch.float32, device=dev),
                torch.empty((nq, k_out), dtype=torch.int64, device=dev))
     nat.call("hiprag_merge_topk_dev", scores64.data_ptr(), ids.data_ptr(), n_parts, nq, k_in, int(k_out),
-             _METRICS[metric], out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream_ptr())
+             int(part_stride), _METRICS[metric], out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream_ptr())
     return out
 
 
