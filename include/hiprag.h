@@ -75,6 +75,13 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
  * float (may be NULL), out_ids_dev [nq,k] int64. */
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+/* Two-phase form of one pass (nq <= 32) for callers that pipeline: begin = query fragments + index scan into
+ * workspace `slot` (0 or 1); finish = group selection, fp64 re-score, top-k, certificate / fallback out of that slot.
+ * begin(slot s) of pass i+2 must be ordered after finish(slot s) of pass i (stream order or an event); the two phases
+ * of one pass may run on different streams if finish waits for begin.  search_dev == begin + finish on slot 0. */
+int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);
+int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
+                                 double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 /* make sure search workspace for (nq<=32 per pass, k) exists so that search_dev never allocates */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);
 int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host); /* row as stored (tests, export) */

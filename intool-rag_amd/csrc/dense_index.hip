@@ -42,8 +42,8 @@ constexpr int kPieceVec4 = 64;
 constexpr int kMaxQ = 32;          // queries per pass
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
-constexpr int kSelPerWave = 8192;  // group maxima filtered by one wave of select_wave_kernel
-constexpr int kExRows = 4096;      // rows per workgroup in the exhaustive path
+constexpr int kExRows = 1024;      // rows per workgroup in the exhaustive path (16 KiB of LDS: it must fit BESIDE a
+                                   // resident scan workgroup, or its launch would serialise behind the next scan)
 constexpr int kMaxK = 1000;
 constexpr int kSlackGroups = 6;
 
@@ -311,6 +311,7 @@ struct FinishArgs {
     float* out32;              // [nq, k] or null
     int64_t* out_ids;          // [nq, k]
     int* flags;                // [nq]
+    int* arrivals;             // [nq] exhaustive-path arrival counters, zeroed here
     unsigned long long* fallback_counter;
     int64_t ntotal, id_base, ncand;  // ncand = nchunks*K1
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
@@ -421,24 +422,30 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
             }
         }
         a.flags[q] = flag;
+        a.arrivals[q] = 0;
         if (flag) atomicAdd(a.fallback_counter, 1ull);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // K2b (fast form, K' + 1 <= 64, i.e. k <= 57): the same stages as finish_kernel, but every selection runs on the
-// wave-resident sorted list of topk_device.h instead of barrier-per-round argmax: wave 0 merges the per-wave
-// winners of select_wave_kernel, all four waves re-score the K' groups in fp64, wave 0 picks the final top-k.
+// wave-resident sorted lists of topk_device.h instead of barrier-per-round argmax.  One workgroup of 16 waves per
+// query: (1) each wave reduces 1/16 of select_wave_kernel's winners to its own top-K1, wave 0 merges the 16 lists;
+// (2) the K' selected groups are re-scored in fp64, one group per wave at a time; (3) wave 0 picks the final top-k
+// of the 4*K' exact scores and evaluates the certificate.  NPL = candidates per lane in stage (1).
 // ------------------------------------------------------------------------------------------------------
-template <int METRIC>
-__global__ __launch_bounds__(kSelThreads) void finish_wave_kernel(FinishArgs a)
+constexpr int kFinWaves = 16;
+template <int METRIC, int NPL>
+__global__ __launch_bounds__(kFinWaves * 64) void finish_wave_kernel(FinishArgs a)
 {
     extern __shared__ unsigned char smem[];
     u64* selk = reinterpret_cast<u64*>(smem);            // [64] packed winners (group maxima)
-    u64* candk = selk + 64;                              // [256] fp64 keys of re-scored rows
+    u64* lists = selk + 64;                              // [kFinWaves * 64] per-wave lists of stage (1)
+    u64* candk = lists + kFinWaves * 64;                 // [256] fp64 keys of re-scored rows
     i64* candi = reinterpret_cast<i64*>(candk + 256);    // [256] row ids
     double* dred = reinterpret_cast<double*>(candi + 256);
-    float* qv = reinterpret_cast<float*>(dred + kSelThreads / 64);
+    float* qv = reinterpret_cast<float*>(dred + kFinWaves);
+    constexpr int NT = kFinWaves * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_wave_kernel(FinishArgs a)
     const int K1 = a.Kp + 1;
 
     double qpart = 0.0;
-    for (int c = tid; c < dpad; c += kSelThreads) {
+    for (int c = tid; c < dpad; c += NT) {
         float v = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
         qv[c] = v;
         qpart += (double)v * (double)v;
@@ -455,28 +462,37 @@ __global__ __launch_bounds__(kSelThreads) void finish_wave_kernel(FinishArgs a)
     for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
     if (lane == 0) dred[wave] = qpart;
 
-    if (wave == 0) {
+    {   // stage (1a): this wave's share of the candidates
         const u64* sk = a.ck + (int64_t)q * a.ncand;
         const i64* si = a.ci + (int64_t)q * a.ncand;
-        WaveListPacked L;
-        L.init();
-        u64 tau = 0;
-        for (int64_t base = 0; base < a.ncand; base += 64) {
-            const int64_t i = base + lane;
-            u64 c = 0;
+        u64 c[NPL];
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int64_t i = ((int64_t)wave * NPL + n) * 64 + lane;
+            c[n] = 0;
             if (i < a.ncand) {
                 const u64 kk = sk[i];
-                if (kk != 0) c = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
+                if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
             }
-            tau = L.offer(c, K1, tau);
         }
+        WaveListPacked L;
+        wave_topk_packed<NPL>(c, K1, L);
+        lists[wave * 64 + lane] = lane < K1 ? L.e : 0;
+    }
+    __syncthreads();
+    if (wave == 0) {  // stage (1b): merge the 16 lists
+        u64 c[kFinWaves];
+#pragma unroll
+        for (int n = 0; n < kFinWaves; ++n) c[n] = lists[n * 64 + lane];
+        WaveListPacked L;
+        wave_topk_packed<kFinWaves>(c, K1, L);
         selk[lane] = L.e;
     }
     __syncthreads();
     double qn2 = 0.0;
-    for (int w = 0; w < kSelThreads / 64; ++w) qn2 += dred[w];
+    for (int w = 0; w < kFinWaves; ++w) qn2 += dred[w];
 
-    for (int j = wave; j < 64; j += kSelThreads / 64) {   // 64 slots x 4 rows = the 256 candidate entries
+    for (int j = wave; j < 64; j += kFinWaves) {   // 64 slots x 4 rows = the 256 candidate entries
         u64 key = 0;
         i64 row = -1;
         if (j < a.Kp) {
@@ -494,35 +510,44 @@ __global__ __launch_bounds__(kSelThreads) void finish_wave_kernel(FinishArgs a)
     }
     __syncthreads();
 
-    if (wave == 0) {
+    if (wave == 0) {  // stage (3)
+        u64 ck4[4];
+        i64 ci4[4];
+        u64 m = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            ck4[n] = candk[n * 64 + lane];
+            ci4[n] = candi[n * 64 + lane];
+            m = ck4[n] > m ? ck4[n] : m;
+        }
+        const u64 t0 = wave_kth_of_lanes(m, a.k);   // k lanes hold a key >= t0: nothing below t0 can reach the top k
         WaveListPair F;
         F.init();
 #pragma unroll
-        for (int base = 0; base < 256; base += 64) F.offer(candk[base + lane], candi[base + lane], a.k);
+        for (int n = 0; n < 4; ++n) F.offer(ck4[n] >= t0 ? ck4[n] : 0ull, ci4[n], a.k);
         if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
         const u64 kth_key = readlane_u64(F.k, a.k - 1);
         if (lane == 0) {
             int flag = 0;
             const u64 bk = selk[a.Kp];  // best group NOT re-scored
             if (bk != 0) {
-                const float m = packed_value(bk);
-                if (m != -INFINITY) {
-                    const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
-                    const double qn = sqrt(qn2);
-                    const double u = 5.9604644775390625e-08;  // 2^-24
-                    double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
-                    double kth_sel;
-                    if (METRIC == HIPRAG_METRIC_IP) {
-                        kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
-                    } else {
-                        eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
-                        kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
-                        eps += 4.0 * u * qn2;
-                    }
-                    if (!(kth_sel > (double)m + eps)) flag = 1;
+                const float m32 = packed_value(bk);
+                const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
+                const double qn = sqrt(qn2);
+                const double u = 5.9604644775390625e-08;  // 2^-24
+                double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
+                double kth_sel;
+                if (METRIC == HIPRAG_METRIC_IP) {
+                    kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
+                } else {
+                    eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
+                    kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
+                    eps += 4.0 * u * qn2;
                 }
+                if (!(kth_sel > (double)m32 + eps)) flag = 1;
             }
             a.flags[q] = flag;
+            a.arrivals[q] = 0;
             if (flag) atomicAdd(a.fallback_counter, 1ull);
         }
     }
@@ -535,7 +560,8 @@ struct ExArgs {
     const float4* xb;
     const float* q;
     const int* flags;
-    u64* ek;       // [nq, nslices*kk]
+    int* arrivals;  // [nq] zeroed by the finish kernel of the same pass
+    u64* ek;        // [nq, nslices*kk]
     i64* ei;
     double* out64;
     float* out32;
@@ -544,14 +570,20 @@ struct ExArgs {
     int d, P, k, kk, nslices, nq;
 };
 
+// One launch: workgroup s re-scores rows [s*kExRows, +kExRows) of every FLAGGED query in fp64 and publishes its best
+// kk; the last workgroup to arrive for a query (device-scope counter behind __threadfence) merges the slices and
+// overwrites the query's results.  Unflagged passes cost one tiny launch: every workgroup reads nq flags and exits.
 template <int METRIC>
-__global__ __launch_bounds__(kSelThreads) void exhaustive_scan_kernel(ExArgs a)
+__global__ __launch_bounds__(kSelThreads) void exhaustive_kernel(ExArgs a)
 {
     extern __shared__ unsigned char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
-    i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
-    KeyId* red = reinterpret_cast<KeyId*>(ids + kSelChunk);
+    i64* ids = reinterpret_cast<i64*>(keys + kExRows);
+    u64* selk = reinterpret_cast<u64*>(ids + kExRows);
+    i64* seli = reinterpret_cast<i64*>(selk + a.k);
+    KeyId* red = reinterpret_cast<KeyId*>(seli + a.k);
     float* qv = reinterpret_cast<float*>(red + 2 * (kSelThreads / 64));
+    int* ticket = reinterpret_cast<int*>(qv + a.P * 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dpad = a.P * 8;
     const int64_t row_base = (int64_t)blockIdx.x * kExRows;
@@ -572,29 +604,35 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_scan_kernel(ExArgs a)
             if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
         }
         __syncthreads();
-        u64* ok = a.ek + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
-        i64* oi = a.ei + ((int64_t)q * a.nslices + blockIdx.x) * a.kk;
+        const int64_t M = (int64_t)a.nslices * a.kk;
+        u64* ok = a.ek + (int64_t)q * M + (int64_t)blockIdx.x * a.kk;
+        i64* oi = a.ei + (int64_t)q * M + (int64_t)blockIdx.x * a.kk;
         wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
+        // Publish this slice, then take a ticket (cdna_hip_programming.md Guideline 16, counter form): stores drained by
+        // their wave -> workgroup barrier -> one lane: agent-scope release, explicit drain, relaxed agent atomic.  The
+        // last arriver acquires once, and the barrier after it holds every wave's loads behind the invalidate.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(a.arrivals + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == a.nslices - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *ticket = t;
+        }
+        __syncthreads();
+        if (*ticket == a.nslices - 1) {  // last arriver merges
+            const u64* sk = a.ek + (int64_t)q * M;
+            const i64* si = a.ei + (int64_t)q * M;
+            wg_stream_topk<kSelThreads, kExRows>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, M, a.k, keys, ids,
+                                                 red, selk, seli);
+            for (int r = tid; r < a.k; r += kSelThreads)
+                write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + r, selk[r], seli[r], a.id_base);
+        }
     }
-}
-
-template <int METRIC>
-__global__ __launch_bounds__(kSelThreads) void exhaustive_merge_kernel(ExArgs a)
-{
-    const int q = blockIdx.x;
-    if (!a.flags[q]) return;
-    extern __shared__ unsigned char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    i64* ids = reinterpret_cast<i64*>(keys + kSelChunk);
-    u64* selk = reinterpret_cast<u64*>(ids + kSelChunk);
-    i64* seli = reinterpret_cast<i64*>(selk + a.k);
-    KeyId* red = reinterpret_cast<KeyId*>(seli + a.k);
-    const int64_t M = (int64_t)a.nslices * a.kk;
-    const u64* sk = a.ek + (int64_t)q * M;
-    const i64* si = a.ei + (int64_t)q * M;
-    wg_stream_topk<kSelThreads>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, M, a.k, keys, ids, red, selk, seli);
-    for (int r = threadIdx.x; r < a.k; r += kSelThreads)
-        write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + r, selk[r], seli[r], a.id_base);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -608,7 +646,10 @@ struct DenseIndex {
     int n_cu = 256;
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    DevBuf gmax, qf, ck, ci, flags, ek, ei, qbuf, o64, o32, oid;
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei; };
+    static constexpr int kSlots = 2;   // two passes may be in flight (scan of pass i+1 beside the finish of pass i)
+    Workspace ws[kSlots];
+    DevBuf qbuf, o64, o32, oid;
     int ws_k = 0;
     int64_t ws_blocks = 0;
     // stats
@@ -715,32 +756,31 @@ struct DenseIndex {
         const int K1 = kprime(kk) + 1;
         const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
         const int ekk = std::min(kk, kExRows);
-        int32_t rc;
-        if ((rc = gmax.reserve((size_t)kMaxQ * gstride * sizeof(float)))) return rc;
-        if ((rc = qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
         const int64_t nlists = std::max(nchunks, ((gstride + kSelPerWave - 1) / kSelPerWave + 3) / 4 * 4);
-        if ((rc = ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
-        if ((rc = ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
-        if ((rc = flags.reserve(kMaxQ * sizeof(int)))) return rc;
-        if ((rc = ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
-        if ((rc = ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
+        for (Workspace& w : ws) {
+            int32_t rc;
+            if ((rc = w.gmax.reserve((size_t)kMaxQ * gstride * sizeof(float)))) return rc;
+            if ((rc = w.qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
+            if ((rc = w.ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
+            if ((rc = w.ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
+            if ((rc = w.flags.reserve(2 * kMaxQ * sizeof(int)))) return rc;  // flags[kMaxQ] + arrivals[kMaxQ]
+            if ((rc = w.ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
+            if ((rc = w.ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
+        }
         ws_k = kk;
         ws_blocks = nbb;
         return HIPRAG_OK;
     }
 
+    // phase 1 of a pass (<= kMaxQ queries): query fragments + the scan, into workspace `slot`
     template <int METRIC>
-    int32_t run_pass(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    int32_t scan_pass(const float* q_dev, int nq, int slot, hipStream_t st)
     {
+        Workspace& w = ws[slot];
         const int64_t nb = nblocks();
-        const int64_t gstride = ws_blocks * 8;
-        const int64_t ngroups = nb * 8;
-        const int Kp = kprime(k), K1 = Kp + 1;
-        const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
-
         ScanArgs sa;
-        sa.xb = xb.as<float4>(); sa.qf = qf.as<float4>(); sa.norms = norms.as<float>(); sa.gmax = gmax.as<float>();
-        sa.gstride = gstride; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
+        sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
+        sa.gstride = ws_blocks * 8; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         const char* vs = getenv("HIPRAG_SCAN_VARIANT");  // timing experiments only (variants 1 and 6 give wrong scores)
         const int variant = vs ? atoi(vs) : 0;
         int NW = 8;
@@ -748,36 +788,61 @@ struct DenseIndex {
         if (variant == 1) scan = scan_kernel<METRIC, 8, 1>;
         if (variant == 2) { scan = scan_kernel<METRIC, 16, 0>; NW = 16; }
         if (variant == 6) scan = scan_kernel<METRIC, 8, 6>;
-        if (variant == 8) scan = scan_kernel<METRIC, 8, 0, 32>;
-        if (variant == 11) { scan = scan_kernel<METRIC, 4, 0, 32>; NW = 4; }
         const size_t scan_lds = (size_t)P * 1024;
         HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)scan_lds));
         hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
-                           qf.as<float4>());
-        const int slot = (int)(ev_count % kEvRing);
-        if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * slot], st));
+                           w.qf.as<float4>());
+        const int ev = (int)(ev_count % kEvRing);
+        if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
         if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
-        if (timing) { HR_CHECK_HIP(hipEventRecord(evs[2 * slot + 1], st)); ++ev_count; }
+        if (timing) { HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st)); ++ev_count; }
+        HR_CHECK_HIP(hipGetLastError());
+        ++passes;
+        queries += nq;
+        return HIPRAG_OK;
+    }
+
+    // phase 2: group selection, fp64 re-score, final top-k + certificate, exhaustive fallback; reads workspace `slot`
+    template <int METRIC>
+    int32_t finish_pass(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        Workspace& w = ws[slot];
+        const int64_t nb = nblocks();
+        const int64_t gstride = ws_blocks * 8;
+        const int64_t ngroups = nb * 8;
+        const int Kp = kprime(k), K1 = Kp + 1;
+        const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
+        int* flags = w.flags.as<int>();
+        int* arrivals = flags + kMaxQ;
 
         FinishArgs fa;
-        fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = ck.as<u64>(); fa.ci = ci.as<i64>();
+        fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = w.ck.as<u64>(); fa.ci = w.ci.as<i64>();
         fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
-        fa.flags = flags.as<int>(); fa.fallback_counter = fallback_counter();
+        fa.flags = flags; fa.arrivals = arrivals; fa.fallback_counter = fallback_counter();
         fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp;
-        if (K1 <= 64) {
+        const int64_t sel_waves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
+        const int64_t sel_slices = (sel_waves + 3) / 4;
+        const int64_t wave_cand = sel_slices * 4 * K1;
+        if (K1 <= 64 && wave_cand <= (int64_t)kFinWaves * 64 * 16) {
             // fast selectors: one wave filters kSelPerWave group maxima against its running K1-th best
-            const int64_t nwaves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
-            const int64_t nslices = (nwaves + 3) / 4;
-            hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)nslices, nq), dim3(256), 0, st,
-                               (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, kSelPerWave, K1, ck.as<u64>(),
-                               ci.as<i64>());
-            fa.ncand = nslices * 4 * K1;
-            const size_t fin_lds = 64 * 8 + 256 * 16 + (kSelThreads / 64) * sizeof(double) + (size_t)P * 8 * sizeof(float);
-            hipLaunchKernelGGL(finish_wave_kernel<METRIC>, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
+            hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)sel_slices, nq), dim3(256), 0, st,
+                               (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
+            fa.ncand = wave_cand;
+            const size_t fin_lds = (64 + kFinWaves * 64 + 256) * 8 + 256 * 8 + kFinWaves * sizeof(double) +
+                                   (size_t)P * 8 * sizeof(float);
+            const int64_t per_lane = (wave_cand + kFinWaves * 64 - 1) / (kFinWaves * 64);
+            void (*fin)(FinishArgs) = finish_wave_kernel<METRIC, 16>;
+            if (per_lane <= 1) fin = finish_wave_kernel<METRIC, 1>;
+            else if (per_lane <= 2) fin = finish_wave_kernel<METRIC, 2>;
+            else if (per_lane <= 4) fin = finish_wave_kernel<METRIC, 4>;
+            else if (per_lane <= 8) fin = finish_wave_kernel<METRIC, 8>;
+            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)fin_lds));
+            hipLaunchKernelGGL(fin, dim3(nq), dim3(kFinWaves * 64), fin_lds, st, fa);
         } else {
             hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
-                               (const float*)gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, ck.as<u64>(), ci.as<i64>());
+                               (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
             fa.ncand = nchunks * K1;
             const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
                                    (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
@@ -788,27 +853,22 @@ struct DenseIndex {
         }
 
         ExArgs ea;
-        ea.xb = xb.as<float4>(); ea.q = q_dev; ea.flags = flags.as<int>(); ea.ek = ek.as<u64>(); ea.ei = ei.as<i64>();
+        ea.xb = xb.as<float4>(); ea.q = q_dev; ea.flags = flags; ea.arrivals = arrivals;
+        ea.ek = w.ek.as<u64>(); ea.ei = w.ei.as<i64>();
         ea.out64 = o64p; ea.out32 = o32p; ea.out_ids = oidp; ea.ntotal = ntotal; ea.id_base = id_base;
         ea.d = d; ea.P = P; ea.k = k; ea.kk = std::min(k, kExRows); ea.nq = nq;
         ea.nslices = (int)std::max<int64_t>(1, (ntotal + kExRows - 1) / kExRows);
-        const size_t ex_lds = (size_t)kSelChunk * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) + (size_t)P * 8 * sizeof(float);
-        auto exs = exhaustive_scan_kernel<METRIC>;
-        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exs), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const size_t ex_lds = (size_t)kExRows * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
+                              (size_t)P * 8 * sizeof(float) + 16;
+        auto exk = exhaustive_kernel<METRIC>;
+        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)ex_lds));
-        hipLaunchKernelGGL(exs, dim3(ea.nslices), dim3(kSelThreads), ex_lds, st, ea);
-        const size_t em_lds = (size_t)kSelChunk * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId);
-        auto exm = exhaustive_merge_kernel<METRIC>;
-        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)em_lds));
-        hipLaunchKernelGGL(exm, dim3(nq), dim3(kSelThreads), em_lds, st, ea);
+        hipLaunchKernelGGL(exk, dim3(ea.nslices), dim3(kSelThreads), ex_lds, st, ea);
         HR_CHECK_HIP(hipGetLastError());
-        ++passes;
-        queries += nq;
         return HIPRAG_OK;
     }
 
-    int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    int32_t prepare(int k)
     {
         int32_t rc = reserve_search(k);
         if (rc) return rc;
@@ -816,15 +876,32 @@ struct DenseIndex {
             evs.resize(2 * kEvRing);
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
         }
+        return HIPRAG_OK;
+    }
+
+    int32_t begin_dev(const float* q_dev, int nq, int slot, hipStream_t st)
+    {
+        return metric == HIPRAG_METRIC_IP ? scan_pass<HIPRAG_METRIC_IP>(q_dev, nq, slot, st)
+                                          : scan_pass<HIPRAG_METRIC_L2>(q_dev, nq, slot, st);
+    }
+
+    int32_t finish_dev(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        return metric == HIPRAG_METRIC_IP ? finish_pass<HIPRAG_METRIC_IP>(q_dev, nq, k, slot, o64p, o32p, oidp, st)
+                                          : finish_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, o64p, o32p, oidp, st);
+    }
+
+    int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        int32_t rc = prepare(k);
+        if (rc) return rc;
         for (int o = 0; o < nq; o += kMaxQ) {
             const int m = std::min(kMaxQ, nq - o);
-            float* o32q = o32p ? o32p + (int64_t)o * k : nullptr;
-            rc = metric == HIPRAG_METRIC_IP
-                     ? run_pass<HIPRAG_METRIC_IP>(q_dev + (int64_t)o * d, m, k, o64p + (int64_t)o * k, o32q,
-                                                  oidp + (int64_t)o * k, st)
-                     : run_pass<HIPRAG_METRIC_L2>(q_dev + (int64_t)o * d, m, k, o64p + (int64_t)o * k, o32q,
-                                                  oidp + (int64_t)o * k, st);
-            if (rc) return rc;
+            const float* qo = q_dev + (int64_t)o * d;
+            if ((rc = begin_dev(qo, m, 0, st))) return rc;
+            if ((rc = finish_dev(qo, m, k, 0, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
+                                 oidp + (int64_t)o * k, st)))
+                return rc;
         }
         return HIPRAG_OK;
     }
@@ -944,6 +1021,29 @@ int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k,
     if (nq == 0) return HIPRAG_OK;
     HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
     return ix->search_dev(q_dev, nq, k, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
+}
+
+int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_begin takes 1..%d queries (got %d)", kMaxQ, nq);
+    HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be 0 or 1");
+    HR_REQUIRE(q_dev, "null device pointer");
+    int32_t rc = ix->prepare(k);
+    if (rc) return rc;
+    return ix->begin_dev(q_dev, nq, slot, (hipStream_t)stream);
+}
+
+int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
+                                 double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_finish takes 1..%d queries (got %d)", kMaxQ, nq);
+    HR_REQUIRE(k > 0 && k <= ix->ws_k, "k=%d was not prepared by search_begin", k);
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be 0 or 1");
+    HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
+    return ix->finish_dev(q_dev, nq, k, slot, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
 }
 
 int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, float* out_scores, int64_t* out_ids)

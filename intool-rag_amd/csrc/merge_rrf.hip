@@ -52,6 +52,53 @@ __global__ __launch_bounds__(kThreads) void merge_topk_kernel(const double* __re
     }
 }
 
+// Fast form for the usual exchange sizes (n_parts * k_in <= 64 * NPL, k_out <= 64): one wave per query, no LDS, so
+// it runs beside a resident scan workgroup.  Lane-best keys give a starting threshold; then filter-and-insert.
+template <int METRIC, int NPL>
+__global__ __launch_bounds__(64) void merge_wave_kernel(const double* __restrict__ in_s, const i64* __restrict__ in_i,
+                                                       int n_parts, int nq, int k_in, int k_out, i64 part_stride,
+                                                       double* __restrict__ out64, float* __restrict__ out32,
+                                                       i64* __restrict__ out_ids)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int M = n_parts * k_in;
+    u64 ck[NPL];
+    i64 ci[NPL];
+    u64 m = 0;
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+        const int i = n * 64 + lane;
+        ck[n] = 0;
+        ci[n] = -1;
+        if (i < M) {
+            const int part = i / k_in, j = i % k_in;
+            const i64 o = (i64)part * part_stride + (i64)q * k_in + j;
+            ci[n] = in_i[o];
+            const double s = in_s[o];
+            ck[n] = ci[n] < 0 ? 0ull : ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+        }
+        m = ck[n] > m ? ck[n] : m;
+    }
+    const u64 t0 = wave_kth_of_lanes(m, k_out);
+    WaveListPair F;
+    F.init();
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) F.offer(ck[n] >= t0 ? ck[n] : 0ull, ci[n], k_out);
+    if (lane < k_out) {
+        const i64 o = (i64)q * k_out + lane;
+        if (F.k == 0) {
+            out64[o] = METRIC == HIPRAG_METRIC_IP ? -DBL_MAX : DBL_MAX;
+            if (out32) out32[o] = METRIC == HIPRAG_METRIC_IP ? -FLT_MAX : FLT_MAX;
+            out_ids[o] = -1;
+        } else {
+            const double s = METRIC == HIPRAG_METRIC_IP ? unord64(F.k) : -unord64(F.k);
+            out64[o] = s;
+            if (out32) out32[o] = (float)s;
+            out_ids[o] = F.id;
+        }
+    }
+}
+
 // One wave per query.  LDS: the two input lists, then the fused (key,id) union.
 __global__ __launch_bounds__(64) void rrf_kernel(const i64* __restrict__ ids_a, const i64* __restrict__ ids_b, int depth_a,
                                                 int depth_b, int k, float c, float w_a, float w_b,
@@ -128,6 +175,20 @@ int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_i
     HR_REQUIRE(metric == HIPRAG_METRIC_IP || metric == HIPRAG_METRIC_L2, "unknown metric %d", metric);
     if (nq == 0) return HIPRAG_OK;
     HR_REQUIRE(in_scores64_dev && in_ids_dev && out_scores64_dev && out_ids_dev, "null device pointer");
+    const int M = n_parts * k_in;
+    if (k_out <= 64 && M <= 64 * 8) {
+        const int npl = (M + 63) / 64;
+        const bool ip = metric == HIPRAG_METRIC_IP;
+        void (*kern)(const double*, const i64*, int, int, int, int, i64, double*, float*, i64*) =
+            npl <= 1 ? (ip ? merge_wave_kernel<0, 1> : merge_wave_kernel<1, 1>)
+          : npl <= 2 ? (ip ? merge_wave_kernel<0, 2> : merge_wave_kernel<1, 2>)
+          : npl <= 4 ? (ip ? merge_wave_kernel<0, 4> : merge_wave_kernel<1, 4>)
+                     : (ip ? merge_wave_kernel<0, 8> : merge_wave_kernel<1, 8>);
+        hipLaunchKernelGGL(kern, dim3(nq), dim3(64), 0, (hipStream_t)stream, in_scores64_dev, (const i64*)in_ids_dev,
+                           n_parts, nq, k_in, k_out, (i64)part_stride, out_scores64_dev, out_scores_dev, (i64*)out_ids_dev);
+        HR_CHECK_HIP(hipGetLastError());
+        return HIPRAG_OK;
+    }
     const size_t lds = (size_t)kTile * 16 + (size_t)k_out * 16 + 2 * (kThreads / 64) * sizeof(KeyId);
     auto kern = metric == HIPRAG_METRIC_IP ? merge_topk_kernel<HIPRAG_METRIC_IP> : merge_topk_kernel<HIPRAG_METRIC_L2>;
     HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -118,7 +118,7 @@ constexpr int kTile = 4096;  // LDS tile entries of the streaming selectors (64 
 // Streaming selection: exact top-K of M candidates produced by load(idx, &key, &id), using one kTile-entry LDS tile
 // (keys/ids) and carrying the running winners between tiles.  Winners land in selk/seli (LDS, K entries, canonical
 // order, exhausted ranks key 0 / id -1).  K must be < kTile.
-template <int NT, typename Load>
+template <int NT, int TILE = kTile, typename Load>
 __device__ __forceinline__ void wg_stream_topk(Load load, i64 M, int K, u64* keys, i64* ids, KeyId* red, u64* selk,
                                                i64* seli)
 {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void wg_stream_topk(Load load, i64 M, int K, u64* key
     i64 o = 0;
     for (;;) {
         i64 rem = M - o;
-        const int take = (int)(rem < (i64)(kTile - filled) ? rem : (i64)(kTile - filled));
+        const int take = (int)(rem < (i64)(TILE - filled) ? rem : (i64)(TILE - filled));
         for (int i = tid; i < take; i += NT) {
             u64 k;
             i64 id;
@@ -192,6 +192,17 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int lane)
     return ((u64)hi << 32) | lo;
 }
 
+// lane j receives lane j-1's value (lane 0 keeps its own): DPP wave_shr:1, two VALU moves instead of LDS-crossbar
+// shuffles.
+__device__ __forceinline__ u32 lane_up1_u32(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 lane_up1_u64(u64 v)
+{
+    return ((u64)lane_up1_u32((u32)(v >> 32)) << 32) | lane_up1_u32((u32)v);
+}
+
 struct WaveListPacked {
     u64 e;  // this lane's entry (0 = empty)
     __device__ __forceinline__ void init() { e = 0; }
@@ -199,13 +210,14 @@ struct WaveListPacked {
     __device__ __forceinline__ void insert(u64 c)
     {
         const int lane = threadIdx.x & 63;
-        const u64 up = __shfl_up(e, 1);
+        const u64 up = lane_up1_u64(e);
         const bool before = c > e;
         const bool before_prev = lane > 0 && c > up;
         if (before) e = before_prev ? up : c;
     }
     __device__ __forceinline__ u64 kth(int K) const { return readlane_u64(e, K - 1); }
-    // Offer every lane's candidate (0 = nothing) against threshold tau (the current K-th entry); returns the new tau.
+    // Offer every lane's candidate (0 = nothing) against threshold tau: candidates must be > tau to enter, and tau
+    // rises to the K-th entry once the list holds K entries above it.  Returns the new tau.
     __device__ __forceinline__ u64 offer(u64 c, int K, u64 tau)
     {
         unsigned long long mask = __ballot(c > tau);
@@ -215,7 +227,8 @@ struct WaveListPacked {
             const u64 cj = readlane_u64(c, j);
             if (cj > tau) {  // wave-uniform
                 insert(cj);
-                tau = kth(K);
+                const u64 kk = kth(K);
+                tau = kk > tau ? kk : tau;
             }
         }
         return tau;
@@ -229,8 +242,8 @@ struct WaveListPair {
     __device__ __forceinline__ void insert(u64 ck, i64 cid)
     {
         const int lane = threadIdx.x & 63;
-        const u64 upk = __shfl_up(k, 1);
-        const i64 upi = __shfl_up(id, 1);
+        const u64 upk = lane_up1_u64(k);
+        const i64 upi = (i64)lane_up1_u64((u64)id);
         const bool before = key_before(ck, cid, k, id);
         const bool before_prev = lane > 0 && key_before(ck, cid, upk, upi);
         if (before) {
@@ -238,7 +251,7 @@ struct WaveListPair {
             id = before_prev ? upi : cid;
         }
     }
-    // Offer every lane's candidate (key 0 = nothing); K-th entry is the threshold.
+    // Offer every lane's candidate (key 0 = nothing); the K-th entry is the threshold.
     __device__ __forceinline__ void offer(u64 ck, i64 cid, int K)
     {
         u64 tk = readlane_u64(k, K - 1);
@@ -258,37 +271,88 @@ struct WaveListPair {
     }
 };
 
-// Level-1 selector, K1 <= 64: grid (nslices, nq), 256 threads = 4 independent waves; wave w of slice s filters the
-// contiguous elements [ (4s+w)*per_wave, +per_wave ) of query q's float array and writes its sorted top-K1 as
-// (key = ord32(v) << 32, id = index) to ck/ci[q][(4s+w)*K1 ..].  POSITIVE_ONLY drops v <= 0.
-template <bool POSITIVE_ONLY>
-__global__ __launch_bounds__(256) void select_wave_kernel(const float* __restrict__ vals, i64 stride, i64 n_total,
-                                                         int per_wave, int K1, u64* __restrict__ ck, i64* __restrict__ ci)
+// Largest t among the 64 lane values m (0 = none) such that at least K lanes hold a value >= t; 0 if fewer than K
+// lanes are non-empty.  K distinct lanes with value >= t prove t is a lower bound of the K-th largest element of
+// whatever population the lane values were drawn from, so (t - 1) is a safe starting threshold for offer().
+__device__ __forceinline__ u64 wave_kth_of_lanes(u64 m, int K)
 {
+    u64 best = 0;
+    for (int j = 0; j < 64; ++j) {
+        const u64 mj = readlane_u64(m, j);
+        const int cnt = __popcll(__ballot(m >= mj));
+        if (mj != 0 && cnt >= K && mj > best) best = mj;
+    }
+    return best;
+}
+
+// Exact top-K (K <= 64) of per-lane candidate arrays c[0..N) (packed keys, 0 = none) into a sorted wave list.
+template <int N>
+__device__ __forceinline__ void wave_topk_packed(const u64 (&c)[N], int K, WaveListPacked& L)
+{
+    u64 m = 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) m = c[n] > m ? c[n] : m;
+    const u64 t0 = wave_kth_of_lanes(m, K);
+    u64 tau = t0 ? t0 - 1 : 0;
+    L.init();
+#pragma unroll
+    for (int n = 0; n < N; ++n) tau = L.offer(c[n], K, tau);
+}
+
+// Level-1 selector, K1 <= 64: grid (nslices, nq), 256 threads = 4 independent waves; wave w of slice s filters the
+// contiguous kSelPerWave elements [(4s+w)*kSelPerWave, ...) of query q's float array (all loads issued up-front) and
+// writes its sorted top-K1 as (key = ord32(v) << 32, id = index) to ck/ci[q][(4s+w)*K1 ..].
+// POSITIVE_ONLY drops v <= 0.  `stride` and the array base must be 16-byte aligned multiples of 4 floats.
+constexpr int kSelPerWave = 4096;
+template <bool POSITIVE_ONLY>
+__global__ __launch_bounds__(256) void select_wave_kernel(const float* __restrict__ vals, i64 stride, i64 n_total, int K1,
+                                                         u64* __restrict__ ck, i64* __restrict__ ci)
+{
+    constexpr int NV = kSelPerWave / 256;  // float4 loads per lane
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.y;
     const i64 wave = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     const i64 nwaves = (i64)gridDim.x * 4;
-    const i64 lo = wave * per_wave;
-    i64 hi = lo + per_wave;
-    if (hi > n_total) hi = n_total;
+    const i64 lo = wave * kSelPerWave;
     const float* src = vals + (i64)q * stride;
+    float v[NV * 4];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const i64 i = lo + it * 256 + lane * 4;
+        float4 x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (i + 3 < n_total) {
+            x = *reinterpret_cast<const float4*>(src + i);
+        } else {
+            if (i + 0 < n_total) x.x = src[i + 0];
+            if (i + 1 < n_total) x.y = src[i + 1];
+            if (i + 2 < n_total) x.z = src[i + 2];
+        }
+        v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
+    }
+    // float-domain pre-threshold: K1-th largest of the 64 lane maxima (padding / excluded values are -inf)
+    float m = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NV * 4; ++n) {
+        const float x = (POSITIVE_ONLY && !(v[n] > 0.f)) ? -INFINITY : v[n];
+        m = fmaxf(m, x);
+    }
+    const u32 mo = m == -INFINITY ? 0u : ord32(m);
+    u32 best = 0;
+    for (int j = 0; j < 64; ++j) {
+        const u32 mj = (u32)__builtin_amdgcn_readlane((int)mo, j);
+        const int cnt = __popcll(__ballot(mo >= mj));
+        if (mj != 0 && cnt >= K1 && mj > best) best = mj;
+    }
+    // elements with ord32(v) >= best can still be among the top K1; everything else is rejected by one compare
     WaveListPacked L;
     L.init();
-    u64 tau = 0;
-    for (i64 base = lo; base < hi; base += 256) {
-        u64 c[4];
+    u64 tau = best ? ((u64)best << 32) - 1 : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const i64 i = base + u * 64 + lane;
-            c[u] = 0;
-            if (i < hi) {
-                const float v = src[i];
-                if (!POSITIVE_ONLY || v > 0.f) c[u] = pack_key(v, (u32)i);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tau = L.offer(c[u], K1, tau);
+    for (int n = 0; n < NV * 4; ++n) {
+        const i64 i = lo + (n >> 2) * 256 + lane * 4 + (n & 3);
+        u64 c = 0;
+        if (v[n] != -INFINITY && (!POSITIVE_ONLY || v[n] > 0.f)) c = pack_key(v[n], (u32)i);
+        tau = L.offer(c, K1, tau);
     }
     if (lane < K1) {
         const i64 o = ((i64)q * nwaves + wave) * K1 + lane;

@@ -104,6 +104,17 @@ class HipFlatIndex:
                  _stream_ptr())
         return s64, s32, ids
 
+    def search_begin(self, q, k: int, slot: int = 0) -> None:
+        """Phase 1 of a pass (<= 32 queries): enqueue query fragments + the index scan into workspace `slot`."""
+        nat.call("hipidx_search_begin_dev", self._h, q.data_ptr(), q.shape[0], int(k), int(slot), _stream_ptr())
+
+    def search_finish(self, q, k: int, slot: int, out):
+        """Phase 2: selection, fp64 re-score, top-k, certificate; `out` = (scores64, scores32, ids) CUDA tensors."""
+        s64, s32, ids = out
+        nat.call("hipidx_search_finish_dev", self._h, q.data_ptr(), q.shape[0], int(k), int(slot), s64.data_ptr(),
+                 s32.data_ptr() if s32 is not None else None, ids.data_ptr(), _stream_ptr())
+        return out
+
     def reserve_search(self, k: int) -> None:
         nat.call("hipidx_reserve_search", self._h, int(k))
 

@@ -184,3 +184,33 @@ def test_device_api_and_merge_of_emulated_shards(gpu):
         assert np.array_equal(m32.cpu().numpy(), fs)          # bit for bit
         es, ei = ho.flat_search(x, q, k, metric)
         assert np.array_equal(fi, ei)
+
+
+def test_two_stream_pipeline_matches_oracle(gpu):
+    """ShardedFlatIndex (world 1) keeps one batch in flight over two streams / two workspace slots."""
+    import torch
+    from hiprag import HipFlatIndex
+    from hiprag.sharded import ShardedFlatIndex
+    n, d, k = 9000, 512, 10
+    x = ho.synthetic_vectors(n, d, seed=31)
+    q = ho.synthetic_queries(32 * 7 + 5, d, seed=32)
+    ix = HipFlatIndex(d, "ip")
+    ix.add(x)
+    sh = ShardedFlatIndex(ix, 0)
+    qd = torch.from_numpy(q).cuda()
+    tickets, outs = None, []
+    for o in range(0, q.shape[0], 32):
+        t = sh.search_begin(qd[o:o + 32], k)
+        if tickets is not None:
+            outs.append(sh.search_end(tickets))
+        tickets = t
+    outs.append(sh.search_end(tickets))
+    torch.cuda.synchronize()
+    ids = torch.cat([o[2] for o in outs]).cpu().numpy()
+    s32 = torch.cat([o[1] for o in outs]).cpu().numpy()
+    es, ei = ho.flat_search(x, q, k, ho.METRIC_IP)
+    assert np.array_equal(ids, ei)
+    assert np.allclose(s32, es, rtol=0, atol=TOL)
+    s64b, s32b, idsb = sh.search_device(qd, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(idsb.cpu().numpy(), ei)
