@@ -1,0 +1,191 @@
+"""
+rag/query/retriever.py -- the retriever the north star names; with hybrid search off it is the reference's
+PageLevelRetriever (rag/query/page_retriever.py:78-288) step for step:
+
+    embed query (no instruction, :109-110) -> vector search, limit = top_chunks = 50 (:117-121)
+    -> RetrievedChunk list in search order (:123-139) -> group by page in first-seen order (:145-164)
+    -> page score = mean(chunk scores) + min(0.05 * n, 0.15) in Python floats, stable sort descending (:166-213)
+    -> first max_pages pages (:215-236)
+
+With hybrid search on (HYBRID_SEARCH_ENABLED, rag/config.py:43) the chunk list is the reciprocal-rank fusion of the
+dense list and a BM25 list over the same chunks (both depth top_chunks) -- the hybrid the reference's README.md:54-58
+describes but never implements; spec in DESIGN.md.  Fusion order decides which chunks survive; each chunk keeps its
+dense similarity as `score` (0.0 if only the sparse leg found it) so page scores stay on the reference's 0..1 scale,
+and metadata["rrf_score"] / ["bm25_score"] carry the rest.
+
+Dense search, BM25 and RRF run in libhiprag.so; grouping and page ranking are a few dozen Python float operations and
+stay on the host exactly as the reference has them.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+from rag.config import config
+from rag.llm.embeddings.factory import get_embedding_provider
+from rag.logging import logger
+
+
+@dataclass
+class RetrievedChunk:
+    """Retrieved chunk with similarity score (page_retriever.py:25-32)."""
+    chunk_id: str
+    text: str
+    score: float
+    page: int
+    metadata: Dict[str, Any]
+
+
+@dataclass
+class PageRanking:
+    """Page with ranking score and its chunks (page_retriever.py:35-75)."""
+    page: int
+    score: float
+    chunks: List[RetrievedChunk]
+    metadata: Dict[str, Any]
+
+    def get_context_text(self) -> str:
+        lines: List[str] = []
+        hierarchy = []
+        if self.metadata.get("chapter"):
+            hierarchy.append(f"Chapter {self.metadata['chapter']}")
+        if self.metadata.get("section"):
+            hierarchy.append(f"Section {self.metadata['section']}")
+        if self.metadata.get("title"):
+            hierarchy.append(f"{self.metadata['title']}")
+        if hierarchy:
+            lines += [f"[{' | '.join(hierarchy)}]", ""]
+        for chunk in self.chunks:
+            lines += [chunk.text, ""]
+        return "\n".join(lines).strip()
+
+    def to_citation(self) -> Dict[str, Any]:
+        return {
+            "page": self.page,
+            "chapter": self.metadata.get("chapter"),
+            "section": self.metadata.get("section"),
+            "subsection": self.metadata.get("subsection"),
+            "title": self.metadata.get("title"),
+            "source_file": self.metadata.get("source_filename"),
+            "relevance_score": round(self.score, 3),
+        }
+
+
+def group_chunks_by_page(chunks: List[RetrievedChunk]) -> Dict[int, List[RetrievedChunk]]:
+    grouped: Dict[int, List[RetrievedChunk]] = {}
+    for chunk in chunks:
+        grouped.setdefault(chunk.page, []).append(chunk)
+    return grouped
+
+
+def rank_pages(chunks_by_page: Dict[int, List[RetrievedChunk]]) -> List[PageRanking]:
+    rankings = []
+    for page_num, page_chunks in chunks_by_page.items():
+        avg_score = sum(c.score for c in page_chunks) / len(page_chunks)
+        chunk_boost = min(len(page_chunks) * 0.05, 0.15)
+        rankings.append(PageRanking(page=page_num, score=avg_score + chunk_boost, chunks=page_chunks,
+                                    metadata=page_chunks[0].metadata))
+    rankings.sort(key=lambda r: r.score, reverse=True)       # stable: ties keep first-seen page order
+    return rankings
+
+
+class HybridRetriever:
+    """Retrieve and rank at page level; `hybrid=None` follows HYBRID_SEARCH_ENABLED, False = the reference's path."""
+
+    def __init__(self, top_chunks: int = 50, top_pages: int = 5, hybrid: Optional[bool] = False,
+                 rrf_c: float = 60.0, weighted: bool = False):
+        self.top_chunks = top_chunks
+        self.top_pages = top_pages
+        self.hybrid = config.HYBRID_SEARCH_ENABLED if hybrid is None else hybrid
+        self.rrf_c = rrf_c
+        # weighted RRF uses the reference's unused knobs VECTOR_WEIGHT / BM25_WEIGHT (config.py:44-45)
+        self.w_dense, self.w_sparse = (config.VECTOR_WEIGHT, config.BM25_WEIGHT) if weighted else (1.0, 1.0)
+
+    async def retrieve_chunks(self, query: str, project: Optional[str] = None) -> List[RetrievedChunk]:
+        logger.info(f"Retrieving top-{self.top_chunks} chunks for query")
+        embedding_provider = get_embedding_provider()
+        query_embedding = await embedding_provider.embed_single(query)
+        if self.hybrid:
+            search_results = self._hybrid_search(query, query_embedding)
+        else:
+            from rag.storage.hip_index import search_hip_by_vector
+            search_results = await search_hip_by_vector(query_embedding, limit=self.top_chunks, project=project)
+        chunks = []
+        for result in search_results:
+            metadata = {
+                "chapter": result.get("chapter"),
+                "section": result.get("section"),
+                "subsection": result.get("subsection"),
+                "title": result.get("title"),
+                "source_filename": result.get("source_filename"),
+                "doc_id": result.get("doc_id"),
+            }
+            for extra in ("rrf_score", "bm25_score"):
+                if extra in result:
+                    metadata[extra] = result[extra]
+            chunks.append(RetrievedChunk(chunk_id=result.get("chunk_id", "unknown"), text=result.get("text", ""),
+                                         score=result.get("score", 0), page=result.get("page", 0), metadata=metadata))
+        logger.info(f"Retrieved {len(chunks)} chunks")
+        return chunks
+
+    def _hybrid_search(self, query: str, query_embedding: List[float]) -> List[dict]:
+        """dense top-K + BM25 top-K over the same chunk rows -> RRF -> enriched dicts in fusion order."""
+        import numpy as np
+        from hiprag import rrf_fuse
+        from rag.storage.hip_index import enrich, open_first_index
+        from rag.storage.hip_index.sparse import get_sparse_index
+        opened = open_first_index()
+        if opened is None:
+            logger.warning("No HIP indices found")
+            return []
+        reader, doc_id, chunks_list = opened
+        depth = self.top_chunks
+        dense = [(rid, sc) for rid, sc in reader.search(query_embedding, top_k=depth) if 0 <= rid < len(chunks_list)]
+        dense_ids = np.full((1, depth), -1, dtype=np.int64)
+        dense_ids[0, :len(dense)] = [rid for rid, _ in dense]
+        dense_score = {rid: sc for rid, sc in dense}
+        bm25 = get_sparse_index(config.STORAGE_DIR, doc_id, chunks_list)
+        s_scores, s_ids = bm25.search([bm25.terms_of(query)], depth)
+        f_scores, f_ids = rrf_fuse(dense_ids, s_ids, depth, c=self.rrf_c, w_a=self.w_dense, w_b=self.w_sparse)
+        bm25_of = {int(i): float(s) for i, s in zip(s_ids[0], s_scores[0]) if i >= 0}
+        fused = []
+        for rid, fs in zip(f_ids[0], f_scores[0]):
+            if rid < 0:
+                continue
+            rid = int(rid)
+            item = enrich([(rid, dense_score.get(rid, 0.0))], chunks_list, compat_minus_one=False)[0]
+            item["rrf_score"] = float(fs)
+            if rid in bm25_of:
+                item["bm25_score"] = bm25_of[rid]
+            fused.append(item)
+        return fused
+
+    # the three page-level steps keep the reference's method names
+    def group_chunks_by_page(self, chunks: List[RetrievedChunk]) -> Dict[int, List[RetrievedChunk]]:
+        return group_chunks_by_page(chunks)
+
+    def rank_pages(self, chunks_by_page: Dict[int, List[RetrievedChunk]]) -> List[PageRanking]:
+        return rank_pages(chunks_by_page)
+
+    def select_top_pages(self, rankings: List[PageRanking], max_pages: Optional[int] = None) -> List[PageRanking]:
+        max_pages = max_pages or self.top_pages
+        selected = rankings[:max_pages]
+        logger.info(f"Selected {len(selected)} pages from {len(rankings)} candidates")
+        return selected
+
+    async def retrieve_and_rank_pages(self, query: str, project: Optional[str] = None,
+                                      max_pages: Optional[int] = None) -> List[PageRanking]:
+        chunks = await self.retrieve_chunks(query, project)
+        if not chunks:
+            logger.warning("No chunks retrieved")
+            return []
+        return self.select_top_pages(self.rank_pages(self.group_chunks_by_page(chunks)), max_pages)
+
+
+PageLevelRetriever = HybridRetriever      # the reference's class name (page_retriever.py:78)
+
+
+async def retrieve_and_rank_pages(query: str, project: Optional[str] = None, top_pages: int = 5) -> List[PageRanking]:
+    """Convenience function with the reference's signature (page_retriever.py:271-288)."""
+    retriever = HybridRetriever(top_pages=top_pages)
+    return await retriever.retrieve_and_rank_pages(query, project, top_pages)

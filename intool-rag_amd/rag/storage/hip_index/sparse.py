@@ -1,0 +1,34 @@
+"""
+BM25 side index over the same chunk table the dense index uses (row id == position in `{doc_id}_chunks.json`,
+rag/storage/faiss_index.py:175-181), built once per chunk-file version and kept in HBM (hiprag.HipBM25).
+The reference names this leg (README.md:54-58, rag/config.py:43-45) without implementing it; spec in DESIGN.md.
+"""
+from __future__ import annotations
+
+import threading
+from pathlib import Path
+from typing import Any, Dict, List, Tuple
+
+from rag.config import config
+
+_SPARSE_CACHE: Dict[str, Tuple[int, Any]] = {}
+_LOCK = threading.Lock()
+
+
+def get_sparse_index(storage_path: Path, doc_id: str, chunks_list: List[Dict[str, Any]]):
+    from hiprag import HipBM25, build_postings_from_texts
+    key = str(Path(storage_path) / doc_id)
+    with _LOCK:
+        hit = _SPARSE_CACHE.get(key)
+        if hit is not None and hit[0] == id(chunks_list):
+            return hit[1]
+    postings = build_postings_from_texts([c.get("text", "") for c in chunks_list])
+    index = HipBM25(postings, device=config.HIP_DEVICE)
+    with _LOCK:
+        _SPARSE_CACHE[key] = (id(chunks_list), index)
+    return index
+
+
+def clear_sparse_cache() -> None:
+    with _LOCK:
+        _SPARSE_CACHE.clear()

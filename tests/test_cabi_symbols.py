@@ -1,0 +1,45 @@
+"""CPU: libhiprag.so loads and exports every function include/hiprag.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(REPO, "include", "hiprag.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hip[a-z0-9]*_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_surface():
+    names = _declared_functions()
+    for must in ("hipidx_create", "hipidx_add", "hipidx_search", "hipidx_search_dev", "hipidx_search_begin_dev",
+                 "hipidx_search_finish_dev", "hipidx_save", "hipidx_load", "hipbm25_create", "hipbm25_search",
+                 "hiprrf_fuse", "hiprag_merge_topk_dev", "hiprag_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from hiprag import _native as nat
+    assert os.path.exists(nat.LIB_PATH), "build the library first: __graft_entry__.build()"
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} declared in hiprag.h but not exported"
+
+
+def test_python_binding_covers_every_declared_symbol():
+    from hiprag import _native as nat
+    nat.load()
+    assert sorted(nat.exported_symbols()) == _declared_functions()
+
+
+def test_errors_surface_as_exceptions_without_a_gpu_or_with_bad_args():
+    import pytest
+    from hiprag import _native as nat
+    h = ctypes.c_uint64()
+    with pytest.raises(nat.HipRagError) as e:
+        nat.call("hipidx_create", 0, 0, 0, ctypes.byref(h))        # d = 0 is invalid everywhere
+    assert "d must be positive" in str(e.value)
+    with pytest.raises(nat.HipRagError):
+        nat.call("hipidx_destroy", 123456789)

@@ -1,0 +1,190 @@
+"""
+GPU parity of the sparse leg (BM25 TAAT), rank fusion (RRF) and the rag/ overlay's search functions against the CPU
+oracle and the reference's golden outputs.  Bar: ids bit-exact; BM25 / RRF scores bit-exact fp32 (same op order).
+"""
+import asyncio
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hybrid_oracle as ho
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_wrapper_golden.json")))
+
+
+def _gpu_postings(p):
+    from hiprag import PostingsCSR
+    return PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts)
+
+
+@pytest.mark.parametrize("n_docs,n_terms,k", [(20000, 4096, 50), (5000, 512, 10), (300, 64, 7)])
+def test_bm25_taat_matches_oracle_bit_exact(gpu, n_docs, n_terms, k):
+    from hiprag import HipBM25
+    p = ho.synthetic_postings(n_docs, n_terms=n_terms, seed=777)
+    queries = ho.synthetic_sparse_queries(37, n_terms=n_terms, terms_per_query=6, seed=888, min_rank=min(16, n_terms // 4))
+    queries[3] = np.asarray([queries[3][0], queries[3][0], queries[3][1]], dtype=np.uint32)   # duplicate term adds twice
+    queries[4] = np.asarray([], dtype=np.uint32)                                             # empty query
+    queries[5] = np.asarray([n_terms + 5, queries[5][0]], dtype=np.uint32)                   # unknown term is skipped
+    es, ei = ho.bm25_search(p, queries, k)
+    ix = HipBM25(_gpu_postings(p))
+    s, i = ix.search(queries, k)
+    assert np.array_equal(i, ei)
+    assert np.array_equal(s, es)
+    st = ix.stats()
+    assert st["queries"] == len(queries) and st["postings_touched"] > 0
+
+
+def test_bm25_ties_and_zero_scores(gpu):
+    from hiprag import HipBM25, build_postings_from_texts
+    texts = ["alpha beta"] * 40 + ["gamma"] * 5 + ["alpha"] * 3        # many exact score ties
+    p = build_postings_from_texts(texts)
+    ix = HipBM25(p)
+    op = ho.build_postings_from_texts(texts)
+    q = [ix.terms_of("alpha"), ix.terms_of("gamma delta"), ix.terms_of("nothing here")]
+    assert q[2] == []
+    s, i = ix.search(q, 10)
+    es, ei = ho.bm25_search(op, q, 10)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    assert i[1].tolist()[:5] == [40, 41, 42, 43, 44] and i[1, 5] == -1     # only 5 docs score > 0
+    assert np.all(i[2] == -1)
+
+
+def test_bm25_doc_range_shards_merge_to_unsharded(gpu):
+    import torch
+    from hiprag import HipBM25, merge_topk_device
+    p = ho.synthetic_postings(9000, n_terms=1024, seed=5)
+    queries = ho.synthetic_sparse_queries(9, n_terms=1024, seed=6)
+    k = 20
+    es, ei = ho.bm25_search(p, queries, k)
+    full = _gpu_postings(p)
+    bounds = [(0, 2500), (2500, 2501), (2501, 9000)]
+    ps, pi = [], []
+    shards = []
+    for lo, hi in bounds:
+        ix = HipBM25(full.shard(lo, hi), id_base=lo)
+        s64, s32, ids = ix.search_device(queries, k)
+        ps.append(s64)
+        pi.append(ids)
+        shards.append(ix)
+    m64, m32, mids = merge_topk_device(torch.stack(ps), torch.stack(pi), k, "ip")
+    torch.cuda.synchronize()
+    assert np.array_equal(mids.cpu().numpy(), ei)
+    assert np.array_equal(m32.cpu().numpy(), es)
+
+
+def test_rrf_matches_oracle_bit_exact(gpu):
+    from hiprag import rrf_fuse
+    rng = np.random.default_rng(11)
+    nq, depth = 33, 50
+    a = np.stack([rng.permutation(400)[:depth] for _ in range(nq)]).astype(np.int64)
+    b = np.stack([rng.permutation(400)[:depth] for _ in range(nq)]).astype(np.int64)
+    a[0, 40:] = -1
+    b[1, :] = -1
+    a[2, :] = -1
+    b[2, :] = -1
+    b[3] = a[3]                                      # identical lists: every fused score ties pairwise by rank
+    for (c, wa, wb, k) in [(60.0, 1.0, 1.0, 10), (60.0, 0.7, 0.3, 50), (1.0, 1.0, 1.0, 100)]:
+        s, i = rrf_fuse(a, b, k, c=c, w_a=wa, w_b=wb)
+        es, ei = ho.rrf_fuse(a, b, k, c=c, w_a=wa, w_b=wb)
+        assert np.array_equal(i, ei)
+        assert np.array_equal(s, es)
+
+
+def test_overlay_search_matches_reference_golden(gpu, tmp_path, monkeypatch):
+    """search_hip_by_vector == the reference's search_faiss_by_vector outputs (ids, order, enrichment, -1 quirk)."""
+    import rag.storage.hip_index as hi
+    g = GOLD["search_faiss_by_vector"]
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path))
+    monkeypatch.setenv("HIP_INDEX_METRIC", "l2")
+    hi.clear_caches()
+    x = np.asarray(g["vectors"], dtype=np.float32)
+    index = hi.create_hip_index([list(map(float, row)) for row in x])           # list-of-lists like the reference
+    hi.save_hip_index(index, str(tmp_path / f"{g['doc_id']}{hi.INDEX_SUFFIX}"))
+    with open(tmp_path / f"{g['doc_id']}_chunks.json", "w") as f:
+        json.dump(g["chunks_json"], f)
+    hi.clear_caches()                                                              # force the load path
+    asyncio.run(hi.initialize_storage())
+    for case in g["cases"]:
+        got = asyncio.run(hi.search_hip_by_vector(case["query"], limit=case["limit"]))
+        exp = case["expected"]
+        assert [r["chunk_id"] for r in got] == [r["chunk_id"] for r in exp]
+        assert [{k: v for k, v in r.items() if k != "score"} for r in got] == \
+               [{k: v for k, v in r.items() if k != "score"} for r in exp]
+        assert np.allclose([r["score"] for r in got], [r["score"] for r in exp], rtol=0, atol=1e-4)
+    reader = hi.HipIndexReader(str(tmp_path / f"{g['doc_id']}{hi.INDEX_SUFFIX}"))
+    assert reader.get_dimension() == x.shape[1] and reader.get_size() == x.shape[0]
+    hi.clear_caches()
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path / "empty"))
+    os.makedirs(tmp_path / "empty")
+    assert asyncio.run(hi.search_hip_by_vector(case["query"], limit=5)) == g["no_index_expected"]
+
+
+class _FakeProvider:
+    """Stands for the encoder so the retriever can be tested without model weights."""
+
+    def __init__(self, table):
+        self.table = table
+
+    async def embed_single(self, text, instruction=None):
+        return [float(v) for v in self.table[text]]
+
+    async def embed_batch(self, texts, instruction=None):
+        return [[float(v) for v in self.table[t]] for t in texts]
+
+    def dimension(self):
+        return len(next(iter(self.table.values())))
+
+
+def test_retriever_dense_and_hybrid_end_to_end(gpu, tmp_path, monkeypatch):
+    import rag.storage.hip_index as hi
+    from rag.storage.hip_index.sparse import clear_sparse_cache
+    import rag.llm.embeddings.factory as fac
+    from rag.query.retriever import HybridRetriever, retrieve_and_rank_pages
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path))
+    hi.clear_caches()
+    clear_sparse_cache()
+    rng = np.random.default_rng(3)
+    n, d = 120, 64
+    x = ho.synthetic_vectors(n, d, seed=41)
+    words = ["invoice", "total", "tax", "customer", "address", "payment", "bank", "date", "item", "price"]
+    texts = [" ".join(rng.choice(words, size=6)) + f" ref{i}" for i in range(n)]
+    chunks = {"total": n, "chunks": [{"chunk_id": f"c_{1 + i // 5:03d}_{i % 5:03d}", "page": 1 + i // 5, "text": texts[i],
+                                      "chunk_index": i % 5} for i in range(n)]}
+    with open(tmp_path / "docB_chunks.json", "w") as f:
+        json.dump(chunks, f)
+    hi.save_hip_index(hi.create_hip_index(x), str(tmp_path / f"docB{hi.INDEX_SUFFIX}"))
+    qtext = "bank payment ref17"
+    qvec = x[17] + 0.1 * ho.synthetic_vectors(1, d, seed=42)[0]
+    qvec /= np.linalg.norm(qvec)
+    fac.set_embedding_provider(_FakeProvider({qtext: qvec}))
+    try:
+        # dense-only == the reference's pipeline restated by the oracle
+        pages = asyncio.run(retrieve_and_rank_pages(qtext, top_pages=5))
+        dist, ids = ho.flat_search(x, qvec.astype(np.float32), 50, ho.METRIC_L2)
+        res = ho.reader_search_transform(dist[0], ids[0])
+        oc = [ho.OChunk(chunks["chunks"][i]["chunk_id"], texts[i], s, chunks["chunks"][i]["page"]) for i, s in res]
+        exp = ho.rank_pages(oc, 5)
+        assert [(p.page, [c.chunk_id for c in p.chunks]) for p in pages] == [(p, cid) for p, _, cid in exp]
+        assert np.allclose([p.score for p in pages], [s for _, s, _ in exp], atol=1e-4)
+        assert pages[0].chunks[0].chunk_id == chunks["chunks"][17]["chunk_id"] or any(
+            c.chunk_id == chunks["chunks"][17]["chunk_id"] for p in pages for c in p.chunks)
+        # hybrid: dense top-50 + BM25 top-50 -> RRF, all three legs checked against the oracle
+        r = HybridRetriever(top_chunks=50, top_pages=5, hybrid=True)
+        got = asyncio.run(r.retrieve_chunks(qtext))
+        op = ho.build_postings_from_texts(texts)
+        qterms = [op.vocab[t] for t in ho.tokenize(qtext) if t in op.vocab]
+        _, sparse_ids = ho.bm25_search(op, [qterms], 50)
+        dense_ids = np.asarray([[i for i, _ in res]], dtype=np.int64)
+        fs, fi = ho.rrf_fuse(dense_ids, sparse_ids, 50)
+        exp_ids = [int(i) for i in fi[0] if i >= 0]
+        assert [c.chunk_id for c in got] == [chunks["chunks"][i]["chunk_id"] for i in exp_ids]
+        assert np.array_equal(np.asarray([c.metadata["rrf_score"] for c in got], np.float32), fs[0][:len(got)])
+        assert got[0].chunk_id == chunks["chunks"][17]["chunk_id"]          # both legs agree on the planted chunk
+    finally:
+        fac.set_embedding_provider(None)
+        hi.clear_caches()
+        clear_sparse_cache()

@@ -1,0 +1,72 @@
+"""CPU: host-side logic of the rag/ overlay against the reference's golden outputs (no GPU needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_wrapper_golden.json")))
+
+
+def test_page_grouping_ranking_selection_match_reference():
+    from rag.query.retriever import HybridRetriever, RetrievedChunk
+    for case in GOLD["page_ranking"]:
+        chunks = [RetrievedChunk(f"c{i}", f"t{i}", s, p, {"title": f"T{p}"}) for i, (s, p) in enumerate(case["chunks"])]
+        r = HybridRetriever(top_pages=case["max_pages"])
+        ranked = r.select_top_pages(r.rank_pages(r.group_chunks_by_page(chunks)), case["max_pages"])
+        got = [{"page": x.page, "score": x.score, "chunk_ids": [c.chunk_id for c in x.chunks],
+                "citation_score": x.to_citation()["relevance_score"]} for x in ranked]
+        assert got == case["expected"]
+
+
+def test_enrich_matches_reference_including_minus_one_quirk():
+    from rag.storage.hip_index import enrich
+    from oracle import hybrid_oracle as ho
+    g = GOLD["search_faiss_by_vector"]
+    x = np.asarray(g["vectors"], dtype=np.float32)
+    chunks = list({c["chunk_id"]: c for c in g["chunks_json"]["chunks"]}.values())
+    for case in g["cases"]:
+        d, i = ho.flat_search(x, np.asarray(case["query"], np.float32), case["limit"], ho.METRIC_L2)
+        res = ho.reader_search_transform(d[0], i[0])           # (id, score) pairs as the reader would return them
+        assert enrich(res, chunks, compat_minus_one=True) == case["expected"]
+        strict = enrich(res, chunks, compat_minus_one=False)
+        assert strict == [e for e, (rid, _) in zip(case["expected"], res) if rid >= 0]
+
+
+def test_context_text_and_citation_shapes():
+    from rag.query.retriever import PageRanking, RetrievedChunk
+    md = {"chapter": "2", "section": "2.1", "title": "Intro", "source_filename": "a.pdf", "subsection": None}
+    p = PageRanking(3, 0.61234, [RetrievedChunk("c", "hello", 0.5, 3, md), RetrievedChunk("d", "world", 0.4, 3, md)], md)
+    assert p.get_context_text() == "[Chapter 2 | Section 2.1 | Intro]\n\nhello\n\nworld"
+    assert p.to_citation() == {"page": 3, "chapter": "2", "section": "2.1", "subsection": None, "title": "Intro",
+                               "source_file": "a.pdf", "relevance_score": 0.612}
+
+
+def test_factory_rejects_unknown_provider(monkeypatch):
+    import rag.llm.embeddings.factory as f
+    f.set_embedding_provider(None)
+    monkeypatch.setenv("EMBEDDING_PROVIDER", "gemini")
+    with pytest.raises(RuntimeError):
+        f.get_embedding_provider()
+    f.set_embedding_provider(None)
+
+
+def test_host_bm25_builder_matches_oracle_spec():
+    from hiprag import build_postings, build_postings_from_texts
+    from oracle import hybrid_oracle as ho
+    texts = ["red apple pie", "apple tart", "Red red wine list", "", "pie pie PIE chart of apple"]
+    a = build_postings_from_texts(texts)
+    b = ho.build_postings_from_texts(texts)
+    assert a.vocab == b.vocab
+    assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.doc_ids, b.doc_ids)
+    assert np.array_equal(a.impacts, b.impacts)                # bit-equal fp32 impacts
+    rng = np.random.default_rng(0)
+    doc = np.sort(rng.integers(0, 500, 20000))
+    term = rng.integers(0, 300, 20000)
+    a = build_postings(doc, term, 500, 300)
+    b = ho.build_postings_from_pairs(doc, term, 500, 300)
+    assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.doc_ids, b.doc_ids)
+    assert np.array_equal(a.impacts, b.impacts)
+    sh = a.shard(100, 350)
+    assert sh.n_docs == 250 and int(sh.offsets[-1]) == int(((a.doc_ids >= 100) & (a.doc_ids < 350)).sum())
