@@ -61,7 +61,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hiprag import HipFlatIndex
-    from hiprag.sharded import ShardedFlatIndex
+    from hiprag.sharded import ShardedFlatIndex, chunks_of_rank
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,7 +81,7 @@ def main():
 
     # ---- build the local shard (rows resident in HBM before anything is timed) ----------------------
     n_chunks = (n_rows + chunk - 1) // chunk
-    my_chunks = [c for c in range(n_chunks) if (c * world) // n_chunks == rank] if world > 1 else list(range(n_chunks))
+    my_chunks = chunks_of_rank(n_chunks, world, rank)
     row_lo = my_chunks[0] * chunk if my_chunks else 0
     index = HipFlatIndex(DIM, "ip", device=local_rank)
     keep_host = (world == 1 and not args.no_cpu_baseline)

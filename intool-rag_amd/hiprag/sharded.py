@@ -26,6 +26,21 @@ def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
     return [(n * r // world, n * (r + 1) // world) for r in range(world)]
 
 
+def chunks_of_rank(n_chunks: int, world: int, rank: int) -> List[int]:
+    """Contiguous chunk ids owned by `rank` when n_chunks generation chunks are dealt to `world` ranks in order."""
+    return [c for c in range(n_chunks) if (c * world) // n_chunks == rank]
+
+
+def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
+    """The ONE collective of a sharded search: every rank contributes `pack` ([2, nq, k] int64 = fp64 score bits and
+    ids) and receives `gathered` ([world, 2, nq, k]).  RCCL ("nccl") gathers into the tensor directly; other backends
+    (gloo in the CPU tests) take the list form over the same memory."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(gathered, pack, group=group, async_op=async_op)
+    return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
+
+
 class ShardedFlatIndex:
     def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None):
         import torch
@@ -70,7 +85,7 @@ class ShardedFlatIndex:
             done.record(side)
             self._slot_done[slot] = done
             if self.world > 1:
-                work = dist.all_gather_into_tensor(gathered, pack, group=self.group, async_op=True)
+                work = all_gather_packed(pack, gathered, self.group, async_op=True)
         return (work, pack, s32, gathered, k, slot, done)
 
     def search_end(self, ticket):

@@ -1,0 +1,124 @@
+"""
+Multi-rank path.  CPU (gloo, world_size 2): the exchange protocol -- shard assignment, the packed [2,nq,k] int64
+layout, the single all-gather and the canonical merge -- with the oracle standing in for the per-rank GPU search.
+GPU (-m gpu): the real thing, two ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device), asserting
+sharded == unsharded == oracle bit for bit through ShardedFlatIndex's two-stream pipeline.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(rank, world, port):
+    for p in (REPO, os.path.join(REPO, "intool-rag_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _cpu_worker(rank, world, port, q_out):
+    import torch
+    dist = _setup(rank, world, port)
+    from hiprag.sharded import all_gather_packed, chunks_of_rank, shard_bounds
+    from oracle import hybrid_oracle as ho
+    try:
+        n, d, nq, k = 4001, 48, 6, 10
+        x = ho.synthetic_vectors(n, d, seed=51)
+        q = ho.synthetic_queries(nq, d, seed=52)
+        lo, hi = shard_bounds(n, world)[rank]
+        for metric in (ho.METRIC_IP, ho.METRIC_L2):
+            _, ids, s64 = ho.flat_search(x[lo:hi], q, k, metric, id_base=lo, return_f64=True)
+            pack = torch.empty((2, nq, k), dtype=torch.int64)
+            pack[0] = torch.from_numpy(s64.view(np.int64))
+            pack[1] = torch.from_numpy(ids)
+            gathered = torch.empty((world, 2, nq, k), dtype=torch.int64)
+            all_gather_packed(pack, gathered, None, async_op=True).wait()
+            parts_s = [gathered[r, 0].numpy().view(np.float64) for r in range(world)]
+            parts_i = [gathered[r, 1].numpy() for r in range(world)]
+            ms, mi = ho.merge_partial_topk(parts_s, parts_i, k, metric)
+            fs, fi, f64 = ho.flat_search(x, q, k, metric, return_f64=True)
+            assert np.array_equal(mi, fi) and np.array_equal(ms, f64)
+        owned = [chunks_of_rank(32, world, r) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(32)) and all(o == list(range(o[0], o[-1] + 1)) for o in owned)
+        q_out.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        q_out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker, world=2, timeout=180):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q_out.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def test_exchange_protocol_world2_gloo_cpu():
+    _run(_cpu_worker, world=2)
+
+
+def test_shard_bounds_cover_and_balance():
+    sys.path.insert(0, os.path.join(REPO, "intool-rag_amd"))
+    from hiprag.sharded import shard_bounds
+    for n in (0, 1, 7, 1_000_000, 10_000_001):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _gpu_worker(rank, world, port, q_out):
+    import torch
+    dist = _setup(rank, world, port)
+    from hiprag import HipFlatIndex
+    from hiprag.sharded import ShardedFlatIndex, shard_bounds
+    from oracle import hybrid_oracle as ho
+    try:
+        torch.cuda.set_device(0)
+        n, d, k = 7001, 256, 10
+        x = ho.synthetic_vectors(n, d, seed=61)
+        q = ho.synthetic_queries(32 * 3 + 7, d, seed=62)
+        lo, hi = shard_bounds(n, world)[rank]
+        for metric in ("ip", "l2"):
+            local = HipFlatIndex(d, metric)
+            local.add(x[lo:hi])
+            sh = ShardedFlatIndex(local, lo)
+            assert sh.world == world
+            s64, s32, ids = sh.search_device(torch.from_numpy(q).cuda(), k)
+            torch.cuda.synchronize()
+            es, ei = ho.flat_search(x, q, k, ho.METRIC_IP if metric == "ip" else ho.METRIC_L2)
+            assert np.array_equal(ids.cpu().numpy(), ei)
+            assert np.array_equal(s32.cpu().numpy(), es)
+        q_out.put((rank, "ok"))
+    except Exception as e:
+        q_out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_index_two_ranks_on_one_gpu(gpu):
+    _run(_gpu_worker, world=2, timeout=300)
