@@ -138,6 +138,40 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
                         int32_t depth_b, int32_t k, float c, float w_a, float w_b, float* out_scores_dev,
                         int64_t* out_ids_dev, void* stream);
 
+/* ---- batch encoder: XLM-RoBERTa-large architecture (BGE-M3 embeddings, bge-reranker-v2-m3 cross-encoder) ---------
+ * forward     <- HuggingFaceEmbeddings.embed_query / embed_documents (sentence-transformers encode, CLS pooling,
+ *                normalize_embeddings=True)            rag/providers/hf/embeddings.py:32-35,54,77
+ * score_pairs <- the cross-encoder the reference only configures (RERANKER_MODEL)      rag/config.py:25-27
+ * Weights are DEVICE pointers owned by the caller (torch tensors) and must outlive the handle: matrices bf16 in
+ * torch.nn.Linear layout [out, in]; biases and LayerNorm parameters fp32.  Token ids / lengths are HOST arrays
+ * ([nseq, max_len] int32, right-padded; lengths include BOS/EOS).  Outputs are DEVICE fp32: forward -> [nseq, hidden]
+ * L2-normalised CLS embeddings (zeros for length-0 rows); score_pairs -> [nseq] logits. */
+typedef struct hipenc_config {
+    int32_t vocab, hidden, layers, heads, ffn, max_pos, pad_id;
+    float ln_eps;
+} hipenc_config;
+typedef struct hipenc_layer_weights {
+    const void *wqkv, *bqkv;     /* [3H, H] bf16 = cat(query, key, value).weight; [3H] f32 */
+    const void *wo, *bo;         /* attention.output.dense */
+    const void *ln1_g, *ln1_b;   /* attention.output.LayerNorm */
+    const void *w1, *b1;         /* intermediate.dense [F, H] */
+    const void *w2, *b2;         /* output.dense [H, F] */
+    const void *ln2_g, *ln2_b;   /* output.LayerNorm */
+} hipenc_layer_weights;
+typedef struct hipenc_weights {
+    const void *word_emb, *pos_emb, *type_emb;   /* [V,H], [max_pos,H], [H] (row 0 of token_type_embeddings) bf16 */
+    const void *emb_ln_g, *emb_ln_b;             /* f32 */
+    const hipenc_layer_weights* layers;          /* host array of `layers` entries */
+    const void *cls_dense_w, *cls_dense_b, *cls_out_w, *cls_out_b; /* optional head: [H,H] bf16, [H] f32, [H] bf16, [1] f32 */
+} hipenc_weights;
+int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, int32_t device, uint64_t* out_handle);
+int32_t hipenc_destroy(uint64_t h);
+int32_t hipenc_forward(uint64_t h, const int32_t* token_ids_host, const int32_t* seq_lens_host, int32_t nseq,
+                       int32_t max_len, float* out_dev, void* stream);
+int32_t hipenc_score_pairs(uint64_t h, const int32_t* token_ids_host, const int32_t* seq_lens_host, int32_t nseq,
+                           int32_t max_len, float* out_logits_dev, void* stream);
+int32_t hipenc_last_flops(uint64_t h, double* out_flops); /* algorithmic FLOPs of the last forward */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,548 @@
+// encoder.hip -- XLM-RoBERTa-large-shaped batch encoder (BGE-M3 / bge-reranker-v2-m3 architecture) on MFMA.
+//
+// Replaces the transformer forward the reference reaches through
+//   rag/providers/hf/embeddings.py:54,77  (LangChain HuggingFaceEmbeddings -> sentence-transformers encode:
+//   CLS pooling + L2 normalisation, normalize_embeddings=True at :34)
+// and supplies the cross-encoder scoring the reference only configures (rag/config.py:25-27).
+//
+// Architecture (post-LN BERT family): embeddings (word + learned position + type) -> LayerNorm -> L x [ QKV projection,
+// 16-head scaled-dot-product attention with key padding mask, output projection + residual + LayerNorm,
+// FFN (H->F, exact-erf GELU, F->H) + residual + LayerNorm ] -> CLS row -> L2 normalise (embedding) or
+// dense+tanh+out_proj (reranker logit).  Weights stay in torch-owned HBM tensors; this file only receives pointers.
+//
+// Kernels (all bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16):
+//   K5  embed_ln_kernel      gather + LayerNorm -> bf16
+//   K6/K8/K9 gemm_bf16_kernel 128x128x64 LDS-tiled GEMM, C = A[M,K] * W[N,K]^T, fused epilogues:
+//            QKV (bias, 1/8 scale on q, head-major q/k and TRANSPOSED v), GELU (bias + erf-GELU), RESID (bias + residual
+//            -> fp32 pre-LayerNorm buffer)
+//   K7  attention_kernel     flash-style: 64 queries x 64-key tiles, online softmax in fp32, P through LDS
+//       layernorm_kernel     fp32 pre-LN rows -> bf16
+//   K10 pool_kernel / rerank_head_kernel
+// LDS tiles are stored k-chunk-major ([k/8][row][8 bf16]) with row ^= (chunk & 7): fragment reads (ds_read_b128) and
+// the staging writes are both bank-conflict free (checked by brute force over the ds_read_b128 lane groups).
+// Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s); flops/token ~ L*(8H^2 + 4HF) + attention.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace hiprag {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __bf16 bf16;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kGemmThreads = 256;
+
+__device__ __forceinline__ int swz_unit(int kc, int row, int rows) { return kc * rows + (row ^ (kc & 7)); }
+
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+struct GemmArgs {
+    const bf16* A;      // [M, K] row-major
+    const bf16* W;      // [N, K] row-major (torch Linear weight)
+    const float* bias;  // [N]
+    int M, N, K;
+    // EPI_QKV
+    bf16* q;            // [nseq, heads, S, 64]
+    bf16* k;            // [nseq, heads, S, 64]
+    bf16* vt;           // [nseq, heads, 64, S]
+    int S, heads, H;
+    // EPI_GELU
+    bf16* out_bf16;     // [M, N]
+    // EPI_RESID
+    const bf16* resid;  // [M, N]
+    float* out_f32;     // [M, N]
+};
+
+template <int EPI>
+__global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
+{
+    __shared__ bf16x8 lds[2][2][BM * BK / 8];  // [buffer][A|B][unit]; 2 x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;    // 2 x 2 waves, 64 x 64 each
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread: chunk c -> row c/8, k-chunk c%8
+    bf16x8 ra[4], rb[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + kGemmThreads * i;
+            const int row = c >> 3, kc = c & 7;
+            ra[i] = *reinterpret_cast<const bf16x8*>(g.A + (size_t)(m0 + row) * g.K + k0 + kc * 8);
+            rb[i] = *reinterpret_cast<const bf16x8*>(g.W + (size_t)(n0 + row) * g.K + k0 + kc * 8);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + kGemmThreads * i;
+            const int row = c >> 3, kc = c & 7;
+            lds[buf][0][swz_unit(kc, row, BM)] = ra[i];
+            lds[buf][1][swz_unit(kc, row, BN)] = rb[i];
+        }
+    };
+
+    const int nk = g.K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);  // global loads fly under this tile's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+            const int kc = ks * 4 + kq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds[buf][0][swz_unit(kc, wr * 64 + i * 16 + r16, BM)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = lds[buf][1][swz_unit(kc, wc * 64 + j * 16 + r16, BN)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + 4*kq + r][n0 + wc*64 + j*16 + r16]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + r16;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + i * 16 + 4 * kq + r;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (EPI == EPI_QKV) {
+                    const int which = n / g.H, hn = n - which * g.H;
+                    const int head = hn >> 6, dd = hn & 63;
+                    const int seq = m / g.S, s = m - seq * g.S;
+                    const size_t hb = ((size_t)seq * g.heads + head);
+                    if (which == 0) g.q[(hb * g.S + s) * 64 + dd] = (bf16)(v * 0.125f);  // 1/sqrt(64), exact
+                    else if (which == 1) g.k[(hb * g.S + s) * 64 + dd] = (bf16)v;
+                    else g.vt[(hb * 64 + dd) * g.S + s] = (bf16)v;
+                } else if (EPI == EPI_GELU) {
+                    v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    g.out_bf16[(size_t)m * g.N + n] = (bf16)v;
+                } else {
+                    v += (float)g.resid[(size_t)m * g.N + n];
+                    g.out_f32[(size_t)m * g.N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over rows of an fp32 [M,H] buffer -> bf16; one wave per row.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16* __restrict__ y, int M, int H,
+                                                       float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) { const float t = xr[c] - mean; v += t * t; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
+    bf16* yr = y + (size_t)row * H;
+    for (int c = lane; c < H; c += 64) yr[c] = (bf16)((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+}
+
+// K5: embeddings.  tokens [nseq, S] (pad beyond len), position id = s + pad_id + 1 for real tokens, pad_id for pads
+// (transformers' create_position_ids_from_input_ids with no interior pads).  One wave per token.
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ tokens, const int* __restrict__ lens, int S,
+                                                      int nseq, const bf16* __restrict__ word, const bf16* __restrict__ pos,
+                                                      const bf16* __restrict__ type0, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16* __restrict__ y, int H, int pad_id,
+                                                      float eps, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    bf16* yr = y + (size_t)row * H;
+    const int seq = row / S, s = row - seq * S;
+    if (seq >= nseq || s >= lens[seq]) {  // padding rows are zeros: they never reach a real token (keys are masked)
+        for (int c = lane; c < H; c += 64) yr[c] = (bf16)0.f;
+        return;
+    }
+    const int tok = tokens[(size_t)seq * S + s];
+    const bf16* w = word + (size_t)tok * H;
+    const bf16* p = pos + (size_t)(s + pad_id + 1) * H;
+    float vals[32];  // H <= 2048
+    float sum = 0.f;
+    int n = 0;
+    for (int c = lane; c < H; c += 64, ++n) {
+        const float t = (float)w[c] + (float)p[c] + (float)type0[c];
+        vals[n] = t;
+        sum += t;
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float var = 0.f;
+    for (int i = 0; i < n; ++i) { const float t = vals[i] - mean; var += t * t; }
+    const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+    n = 0;
+    for (int c = lane; c < H; c += 64, ++n) yr[c] = (bf16)((vals[n] - mean) * rstd * gamma[c] + beta[c]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K7: attention.  grid (S/64, heads, nseq); 4 waves x 16 query rows; keys in tiles of 64.
+// q,k: [nseq, heads, S, 64] (q pre-scaled by 1/8), vt: [nseq, heads, 64, S]; ctx out: [M, H] row-major.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                       const bf16* __restrict__ vt, const int* __restrict__ lens,
+                                                       bf16* __restrict__ ctx, int S, int heads, int H)
+{
+    __shared__ bf16x8 kl[64 * 8];        // K tile  [d/8][key][8], swizzled
+    __shared__ bf16x8 vl[64 * 8];        // V^T tile [key/8][d][8], swizzled
+    __shared__ bf16 pl[4][16][72];       // per-wave P [q][key], rows padded to 144 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int seq = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
+    const int len = lens[seq];
+    if (q0 >= len) return;  // whole query tile is padding
+    const size_t hb = (size_t)seq * heads + head;
+    const bf16* qh = q + hb * S * 64;
+    const bf16* kh = k + hb * S * 64;
+    const bf16* vh = vt + hb * 64 * S;
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(qh + (size_t)(q0 + wave * 16 + r16) * 64 + ks * 32 + kq * 8);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+    const float LOG2E = 1.4426950408889634f;
+
+    for (int kt0 = 0; kt0 < len; kt0 += 64) {
+        __syncthreads();  // previous tile fully consumed
+        // stage K [64 keys][64 d] and V^T [64 d][64 keys]: 512 chunks each, 2 per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 3, kc = c & 7;
+            kl[swz_unit(kc, row, 64)] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kt0 + row) * 64 + kc * 8);
+            vl[swz_unit(kc, row, 64)] = *reinterpret_cast<const bf16x8*>(vh + (size_t)row * S + kt0 + kc * 8);
+        }
+        __syncthreads();
+        // scores: 16 queries x 64 keys per wave
+        f32x4 sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kl[swz_unit(ks * 4 + kq, j * 16 + r16, 64)], sc[j], 0, 0, 0);
+        }
+        // sc[j][r] = score(query 4*kq + r, key kt0 + 16j + r16); mask padded keys
+        float tmax[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax[r] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = kt0 + j * 16 + r16 < len;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!valid) sc[j][r] = -INFINITY;
+                tmax[r] = fmaxf(tmax[r], sc[j][r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) tmax[r] = fmaxf(tmax[r], __shfl_xor(tmax[r], off));
+        }
+        float alpha[4], psum[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mn = fmaxf(mrow[r], tmax[r]);  // finite: key 0 of the first tile is always valid
+            alpha[r] = exp2f((mrow[r] - mn) * LOG2E);
+            mrow[r] = mn;
+            psum[r] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f((sc[j][r] - mrow[r]) * LOG2E);
+                psum[r] += p;
+                pl[wave][4 * kq + r][j * 16 + r16] = (bf16)p;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) psum[r] += __shfl_xor(psum[r], off);
+            lrow[r] = lrow[r] * alpha[r] + psum[r];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's P writes have landed (same-wave visibility)
+        __builtin_amdgcn_wave_barrier();
+        // O += P V : A = P[q][key] (from LDS), B = V^T[d][key]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pl[wave][r16][ks * 32 + kq * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vl[swz_unit(ks * 4 + kq, j * 16 + r16, 64)], o[j], 0, 0, 0);
+        }
+    }
+    // o[j][r] = out(query q0 + wave*16 + 4*kq + r, d = 16j + r16) / l
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + wave * 16 + 4 * kq + r;
+        const float inv = 1.f / lrow[r];
+        bf16* dst = ctx + ((size_t)seq * S + qi) * H + head * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j * 16 + r16] = (bf16)(o[j][r] * inv);
+    }
+}
+
+// K10a: CLS row (token 0 of each sequence) -> L2 normalise -> fp32 [nseq, H]; zero for empty sequences.
+__global__ __launch_bounds__(64) void pool_kernel(const bf16* __restrict__ x, const int* __restrict__ lens, int S, int H,
+                                                 float* __restrict__ out, int normalize)
+{
+    const int seq = blockIdx.x, lane = threadIdx.x;
+    const bf16* xr = x + (size_t)seq * S * H;
+    float ss = 0.f;
+    for (int c = lane; c < H; c += 64) { const float v = (float)xr[c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float inv = (lens[seq] > 0) ? (normalize ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f) : 0.f;
+    for (int c = lane; c < H; c += 64) out[(size_t)seq * H + c] = (float)xr[c] * inv;
+}
+
+// K10b: XLM-R classification head on the CLS row: logit = w_out . tanh(W_dense cls + b_dense) + b_out.
+__global__ __launch_bounds__(256) void rerank_head_kernel(const bf16* __restrict__ x, int S, int H,
+                                                         const bf16* __restrict__ wd, const float* __restrict__ bd,
+                                                         const bf16* __restrict__ wo, const float* __restrict__ bo,
+                                                         float* __restrict__ logits)
+{
+    __shared__ float cls[2048];
+    __shared__ float part[4];
+    const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16* xr = x + (size_t)seq * S * H;
+    for (int c = tid; c < H; c += 256) cls[c] = (float)xr[c];
+    __syncthreads();
+    float acc = 0.f;
+    for (int n = wave; n < H; n += 4) {  // one wave per output feature
+        const bf16* w = wd + (size_t)n * H;
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += (float)w[c] * cls[c];
+        s = wave_sum(s);
+        if (lane == 0) acc += (float)wo[n] * tanhf(s + bd[n]);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (tid == 0) logits[seq] = part[0] + part[1] + part[2] + part[3] + bo[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct Encoder {
+    std::mutex mu;
+    int device = 0;
+    hipenc_config cfg{};
+    hipenc_weights w{};
+    std::vector<hipenc_layer_weights> layers;
+    DevBuf tokens, lens, x, q, k, vt, ctx, pre, ffn, pooled;
+    double flops_last = 0.0;
+
+    int32_t forward(const int32_t* tok_host, const int32_t* lens_host, int nseq, int max_len, float* out_dev, int mode,
+                    hipStream_t st)
+    {
+        const int H = cfg.hidden, F = cfg.ffn, heads = cfg.heads;
+        const int S = ((max_len + 63) / 64) * 64;
+        const int T = nseq * S;
+        const int M = ((T + BM - 1) / BM) * BM;
+        int32_t rc;
+        if ((rc = tokens.reserve((size_t)nseq * S * 4))) return rc;
+        if ((rc = lens.reserve((size_t)nseq * 4))) return rc;
+        if ((rc = x.reserve((size_t)M * H * 2))) return rc;
+        if ((rc = q.reserve((size_t)M * H * 2))) return rc;
+        if ((rc = k.reserve((size_t)M * H * 2))) return rc;
+        if ((rc = vt.reserve((size_t)M * H * 2))) return rc;
+        if ((rc = ctx.reserve((size_t)M * H * 2))) return rc;
+        if ((rc = pre.reserve((size_t)M * H * 4))) return rc;
+        if ((rc = ffn.reserve((size_t)M * F * 2))) return rc;
+        // host staging: pad token rows to S with pad_id
+        std::vector<int32_t> tp((size_t)nseq * S, cfg.pad_id);
+        for (int s = 0; s < nseq; ++s) {
+            if (lens_host[s] < 0 || lens_host[s] > max_len) { set_error("seq_lens[%d]=%d outside [0,%d]", s, lens_host[s], max_len); return HIPRAG_E_INVALID; }
+            for (int t = 0; t < lens_host[s]; ++t) {
+                const int32_t id = tok_host[(size_t)s * max_len + t];
+                if (id < 0 || id >= cfg.vocab) { set_error("token id %d outside the vocabulary", id); return HIPRAG_E_INVALID; }
+                tp[(size_t)s * S + t] = id;
+            }
+        }
+        HR_CHECK_HIP(hipMemcpyAsync(tokens.p, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st));
+        HR_CHECK_HIP(hipMemcpyAsync(lens.p, lens_host, (size_t)nseq * 4, hipMemcpyHostToDevice, st));
+        HR_CHECK_HIP(hipStreamSynchronize(st));  // tp is a local vector
+        HR_CHECK_HIP(hipMemsetAsync(ctx.p, 0, (size_t)M * H * 2, st));  // rows of skipped (all-padding) query tiles
+
+        const bf16* X = x.as<bf16>();
+        hipLaunchKernelGGL(embed_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tokens.as<int>(), lens.as<int>(), S, nseq,
+                           (const bf16*)w.word_emb, (const bf16*)w.pos_emb, (const bf16*)w.type_emb, (const float*)w.emb_ln_g,
+                           (const float*)w.emb_ln_b, x.as<bf16>(), H, cfg.pad_id, cfg.ln_eps, M);
+        for (int l = 0; l < cfg.layers; ++l) {
+            const hipenc_layer_weights& L = layers[l];
+            GemmArgs g{};
+            g.A = X; g.W = (const bf16*)L.wqkv; g.bias = (const float*)L.bqkv; g.M = M; g.N = 3 * H; g.K = H;
+            g.q = q.as<bf16>(); g.k = k.as<bf16>(); g.vt = vt.as<bf16>(); g.S = S; g.heads = heads; g.H = H;
+            // rows >= T exist only as GEMM padding; the QKV scatter must not write them
+            g.M = T;
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3(3 * H / BN, M / BM), dim3(kGemmThreads), 0, st, g);
+            hipLaunchKernelGGL(attention_kernel, dim3(S / 64, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
+                               (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
+                               heads, H);
+            GemmArgs o{};
+            o.A = ctx.as<bf16>(); o.W = (const bf16*)L.wo; o.bias = (const float*)L.bo; o.M = M; o.N = H; o.K = H;
+            o.resid = X; o.out_f32 = pre.as<float>();
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3(H / BN, M / BM), dim3(kGemmThreads), 0, st, o);
+            hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                               (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps);
+            GemmArgs f1{};
+            f1.A = X; f1.W = (const bf16*)L.w1; f1.bias = (const float*)L.b1; f1.M = M; f1.N = F; f1.K = H;
+            f1.out_bf16 = ffn.as<bf16>();
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3(F / BN, M / BM), dim3(kGemmThreads), 0, st, f1);
+            GemmArgs f2{};
+            f2.A = ffn.as<bf16>(); f2.W = (const bf16*)L.w2; f2.bias = (const float*)L.b2; f2.M = M; f2.N = H; f2.K = F;
+            f2.resid = X; f2.out_f32 = pre.as<float>();
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3(H / BN, M / BM), dim3(kGemmThreads), 0, st, f2);
+            hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                               (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps);
+        }
+        if (mode == 0 || mode == 2) {
+            hipLaunchKernelGGL(pool_kernel, dim3(nseq), dim3(64), 0, st, X, (const int*)lens.as<int>(), S, H, out_dev,
+                               mode == 0 ? 1 : 0);
+        } else {
+            if (!w.cls_dense_w || !w.cls_out_w) { set_error("encoder was created without a classification head"); return HIPRAG_E_INVALID; }
+            hipLaunchKernelGGL(rerank_head_kernel, dim3(nseq), dim3(256), 0, st, X, S, H, (const bf16*)w.cls_dense_w,
+                               (const float*)w.cls_dense_b, (const bf16*)w.cls_out_w, (const float*)w.cls_out_b, out_dev);
+        }
+        HR_CHECK_HIP(hipGetLastError());
+        double tok = (double)T;
+        flops_last = tok * cfg.layers * (8.0 * H * H + 4.0 * H * F) + (double)nseq * cfg.layers * 4.0 * S * (double)S * H;
+        return HIPRAG_OK;
+    }
+};
+
+Registry<Encoder>& reg()
+{
+    static Registry<Encoder> r;
+    return r;
+}
+
+}  // namespace
+}  // namespace hiprag
+
+using namespace hiprag;
+
+extern "C" {
+
+int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, int32_t device, uint64_t* out_handle)
+{
+    HR_REQUIRE(cfg && weights && out_handle, "null argument");
+    HR_REQUIRE(cfg->hidden > 0 && cfg->hidden % 128 == 0 && cfg->hidden <= 2048, "hidden must be a multiple of 128, <= 2048");
+    HR_REQUIRE(cfg->heads * 64 == cfg->hidden, "head_dim must be 64 (heads * 64 == hidden)");
+    HR_REQUIRE(cfg->ffn > 0 && cfg->ffn % 128 == 0, "ffn must be a multiple of 128");
+    HR_REQUIRE(cfg->layers > 0 && cfg->vocab > 0 && cfg->max_pos > cfg->pad_id + 1, "bad encoder config");
+    HR_REQUIRE(weights->layers && weights->word_emb && weights->pos_emb && weights->type_emb && weights->emb_ln_g &&
+                   weights->emb_ln_b, "null weight pointer");
+    auto e = std::make_shared<Encoder>();
+    e->device = device;
+    e->cfg = *cfg;
+    e->w = *weights;
+    e->layers.assign(weights->layers, weights->layers + cfg->layers);
+    for (const auto& L : e->layers)
+        HR_REQUIRE(L.wqkv && L.bqkv && L.wo && L.bo && L.ln1_g && L.ln1_b && L.w1 && L.b1 && L.w2 && L.b2 && L.ln2_g && L.ln2_b,
+                   "null layer weight pointer");
+    e->w.layers = nullptr;
+    HR_CHECK_HIP(hipSetDevice(device));
+    *out_handle = reg().put(e);
+    return HIPRAG_OK;
+}
+
+int32_t hipenc_destroy(uint64_t h)
+{
+    auto e = reg().get(h);
+    if (!e) { set_error("unknown encoder handle"); return HIPRAG_E_HANDLE; }
+    {
+        std::lock_guard<std::mutex> guard(e->mu);
+        (void)hipSetDevice(e->device);
+        (void)hipDeviceSynchronize();
+    }
+    reg().erase(h);
+    return HIPRAG_OK;
+}
+
+static int32_t enc_run(uint64_t h, const int32_t* token_ids, const int32_t* seq_lens, int32_t nseq, int32_t max_len,
+                       float* out_dev, int mode, void* stream)
+{
+    auto e = reg().get(h);
+    if (!e) { set_error("unknown encoder handle"); return HIPRAG_E_HANDLE; }
+    std::lock_guard<std::mutex> guard(e->mu);
+    HR_CHECK_HIP(hipSetDevice(e->device));
+    HR_REQUIRE(nseq >= 0 && max_len > 0, "bad batch shape");
+    if (nseq == 0) return HIPRAG_OK;
+    HR_REQUIRE(token_ids && seq_lens && out_dev, "null argument");
+    HR_REQUIRE(max_len + e->cfg.pad_id + 1 < e->cfg.max_pos, "max_len %d exceeds the position table", max_len);
+    return e->forward(token_ids, seq_lens, nseq, max_len, out_dev, mode, (hipStream_t)stream);
+}
+
+int32_t hipenc_forward(uint64_t h, const int32_t* token_ids_host, const int32_t* seq_lens_host, int32_t nseq, int32_t max_len,
+                       float* out_dev, void* stream)
+{
+    return enc_run(h, token_ids_host, seq_lens_host, nseq, max_len, out_dev, 0, stream);
+}
+
+int32_t hipenc_score_pairs(uint64_t h, const int32_t* token_ids_host, const int32_t* seq_lens_host, int32_t nseq,
+                           int32_t max_len, float* out_logits_dev, void* stream)
+{
+    return enc_run(h, token_ids_host, seq_lens_host, nseq, max_len, out_logits_dev, 1, stream);
+}
+
+int32_t hipenc_last_flops(uint64_t h, double* out_flops)
+{
+    auto e = reg().get(h);
+    if (!e) { set_error("unknown encoder handle"); return HIPRAG_E_HANDLE; }
+    HR_REQUIRE(out_flops, "null out");
+    *out_flops = e->flops_last;
+    return HIPRAG_OK;
+}
+
+}  // extern "C"

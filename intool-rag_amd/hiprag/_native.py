@@ -69,6 +69,11 @@ SIGNATURES = {
     "hipbm25_search": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p],
     "hipbm25_search_dev": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     "hipbm25_get_stats": [c_uint64, POINTER(HipBm25Stats)],
+    "hipenc_create": [c_void_p, c_void_p, c_int32, u64p],
+    "hipenc_destroy": [c_uint64],
+    "hipenc_forward": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p],
+    "hipenc_score_pairs": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p],
+    "hipenc_last_flops": [c_uint64, f64p],
     "hiprrf_fuse": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,
                     c_void_p],
     "hiprrf_fuse_dev": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,

@@ -1,0 +1,81 @@
+"""
+GPU parity of the MFMA encoder (hipenc_*) against the fp32 oracle on the SAME bf16-rounded weights.
+Tolerance (bf16 operands, fp32 accumulation, 2..24 layers): cosine >= 0.999 per embedding and max |diff| <= 2.5e-2 on the
+unit-norm outputs; reranker logits within 5e-2 absolute.  The retrieval ids computed FROM these embeddings are then
+exact (dense search is bit-exact for whatever vectors it is given).
+"""
+import numpy as np
+import pytest
+
+from oracle import encoder_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+def _tokens(rng, lens, vocab):
+    return [([0] + rng.integers(3, vocab, size=max(0, n - 2)).tolist() + [2])[:max(n, 0)] if n > 0 else [] for n in lens]
+
+
+def _check(cfg, lens, seed, with_head=False, batch_size=256):
+    import torch
+    from hiprag import HipEncoder, random_state
+    sd = random_state(cfg, seed=seed, with_head=with_head)
+    enc = HipEncoder(cfg, sd, with_head=with_head)
+    rng = np.random.default_rng(seed)
+    toks = _tokens(rng, lens, cfg.vocab)
+    got = enc.encode_tokens(toks, batch_size=batch_size).cpu().numpy()
+    ref = eo.embed_fp32(eo.bf16_round_state(sd), toks, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    for i, t in enumerate(toks):
+        if len(t) == 0:
+            assert np.all(got[i] == 0)
+            continue
+        cos = float(np.dot(got[i], ref[i]))
+        assert cos >= 0.999, (i, len(t), cos)
+        assert np.max(np.abs(got[i] - ref[i])) <= 2.5e-2
+        assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-3
+    return enc, sd, toks, got, ref
+
+
+def test_small_config_mixed_lengths(gpu):
+    from hiprag import EncoderConfig
+    cfg = EncoderConfig(vocab=1000, hidden=256, layers=2, heads=4, ffn=1024, max_pos=600, max_seq_len=512)
+    _check(cfg, [16, 64, 128, 5, 1, 2, 65, 200, 0, 63, 127, 129], seed=1)
+
+
+def test_large_width_two_layers_512_tokens(gpu):
+    from hiprag import EncoderConfig
+    cfg = EncoderConfig(vocab=5000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=600, max_seq_len=512)
+    _check(cfg, [512, 512, 17, 300], seed=2)
+
+
+def test_batching_does_not_change_results(gpu):
+    from hiprag import EncoderConfig
+    cfg = EncoderConfig(vocab=1000, hidden=256, layers=3, heads=4, ffn=512, max_pos=300)
+    lens = [9, 33, 70, 4, 120, 64, 18]
+    enc, sd, toks, got, _ = _check(cfg, lens, seed=5, batch_size=256)
+    again = enc.encode_tokens(toks, batch_size=2).cpu().numpy()
+    assert np.allclose(got, again, atol=2e-3)          # same kernels, different padding: only rounding-order noise
+
+
+def test_reranker_head_logits(gpu):
+    from hiprag import EncoderConfig
+    cfg = EncoderConfig(vocab=1000, hidden=256, layers=2, heads=4, ffn=1024, max_pos=300)
+    enc, sd, toks, _, _ = _check(cfg, [20, 50, 7, 100], seed=7, with_head=True)
+    got = enc.score_tokens(toks).cpu().numpy()
+    ref = eo.rerank_logits_fp32(eo.bf16_round_state(sd), toks, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    assert np.allclose(got, ref, atol=5e-2), (got, ref)
+    assert np.array_equal(np.argsort(-got), np.argsort(-ref)) or np.max(np.abs(np.sort(ref)[1:] - np.sort(ref)[:-1])) < 5e-2
+
+
+def test_bad_inputs_raise(gpu):
+    from hiprag import EncoderConfig, HipEncoder, HipRagError
+    with pytest.raises(HipRagError):
+        HipEncoder(EncoderConfig(vocab=100, hidden=200, layers=1, heads=3, ffn=256, max_pos=64))      # hidden % 128
+    cfg = EncoderConfig(vocab=100, hidden=128, layers=1, heads=2, ffn=128, max_pos=40)
+    enc = HipEncoder(cfg)
+    with pytest.raises(HipRagError):
+        enc.encode_tokens([[0, 500, 2]])                 # token id outside the vocabulary
+    with pytest.raises(HipRagError):
+        enc.encode_tokens([[0] + [5] * 60 + [2]])        # longer than the position table
+    with pytest.raises(ValueError):
+        enc.score_tokens([[0, 5, 2]])                    # no classification head
