@@ -188,3 +188,44 @@ def test_retriever_dense_and_hybrid_end_to_end(gpu, tmp_path, monkeypatch):
         fac.set_embedding_provider(None)
         hi.clear_caches()
         clear_sparse_cache()
+
+
+def test_hip_embedding_provider_and_reranker_follow_reference_behaviour(gpu, monkeypatch):
+    """EmbeddingProvider ABC semantics of rag/providers/hf/embeddings.py:42-88 on the GPU encoder, then rerank."""
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    from oracle import encoder_oracle as eo
+    from rag.llm.embeddings.base import EmbeddingProvider
+    from rag.providers.hip.embeddings import HipEmbeddingProvider
+    from rag.providers.hip.tokenizer import HashTokenizer
+    from rag.query.reranker import CrossEncoderReranker
+    from rag.query.retriever import RetrievedChunk
+    cfg = EncoderConfig(vocab=2000, hidden=256, layers=2, heads=4, ffn=512, max_pos=200, max_seq_len=128)
+    sd = random_state(cfg, seed=9, with_head=True)
+    enc = HipEncoder(cfg, sd, with_head=True)
+    tok = HashTokenizer(cfg.vocab)
+    prov = HipEmbeddingProvider(encoder=enc, tokenizer=tok)
+    assert isinstance(prov, EmbeddingProvider) and prov.dimension() == 256
+    assert asyncio.run(prov.embed_single("")) == [0.0] * 256
+    assert asyncio.run(prov.embed_single("   \n ")) == [0.0] * 256
+    assert asyncio.run(prov.embed_batch([])) == []
+    texts = ["  invoice total\namount ", None, "", "bank payment reference number 17"]
+    vecs = asyncio.run(prov.embed_batch(texts, instruction="ignored", batch_size=3))
+    assert len(vecs) == 4 and all(len(v) == 256 for v in vecs)
+    single = asyncio.run(prov.embed_single(" invoice total\namount"))
+    assert np.allclose(single, vecs[0], atol=2e-3)                    # strip + newline->space: same tokens
+    assert np.allclose(vecs[1], vecs[2], atol=1e-6)                   # None and "" both encode the empty string
+    assert abs(np.linalg.norm(vecs[1]) - 1.0) < 1e-3                  # ...and it is NOT the zero vector (hf :70-77)
+    toks = [tok.encode(t, 128) for t in ["invoice total amount", "", "", "bank payment reference number 17"]]
+    ref = eo.embed_fp32(eo.bf16_round_state(sd), toks, cfg.layers, cfg.heads)
+    assert min(float(np.dot(vecs[i], ref[i])) for i in range(4)) >= 0.999
+    # reranker: order by logit, ties by retrieval order, scores attached
+    rr = CrossEncoderReranker(encoder=enc, tokenizer=tok, top_k=2)
+    chunks = [RetrievedChunk(f"c{i}", t, 0.5, 1, {}) for i, t in
+              enumerate(["bank payment", "tax invoice total", "date item price", "bank"])]
+    out = asyncio.run(rr.rerank("bank payment ref", chunks))
+    pairs = [tok.encode_pair("bank payment ref", c.text, 128) for c in chunks]
+    ref_logits = eo.rerank_logits_fp32(eo.bf16_round_state(sd), pairs, cfg.layers, cfg.heads)
+    got_logits = np.asarray(rr.score("bank payment ref", [c.text for c in chunks]))
+    assert np.allclose(got_logits, ref_logits, atol=5e-2)
+    assert [c.chunk_id for c in out] == [chunks[i].chunk_id for i in sorted(range(4), key=lambda i: (-got_logits[i], i))[:2]]
+    assert all("rerank_score" in c.metadata for c in out)
