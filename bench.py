@@ -9,8 +9,8 @@ resident in HBM: scan (fp32 MFMA, HBM-bound) -> group select -> fp64 re-score + 
 all-gather of the packed partial top-k + canonical merge).
 
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): the 1M rows are sharded row-wise
-across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; one step is kept
-in flight so the exchange of step i overlaps the scan of step i+1.
+across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to three steps are
+in flight so the latency-bound tail of a step (selection, fp64 re-score, exchange, merge) runs beside later scans.
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel = scan_kernel; achieved = algorithmic bytes per launch (rows_local * d_pad * 4,
@@ -105,17 +105,20 @@ def main():
     queries /= queries.norm(dim=1, keepdim=True)
     nb = N_QUERIES // BATCH
 
+    IN_FLIGHT = 3      # steps in flight (the library has 4 workspace slots); results are consumed in order
+
     def run_steps(n, first):
-        """n pipelined steps; the all-gather of step i is in flight while step i+1 scans."""
-        ticket, last = None, None
+        """n pipelined steps: while step i scans, the tails (select / re-score / all-gather / merge) of the previous
+        steps run on their own streams."""
+        from collections import deque
+        pending, last = deque(), None
         for s in range(n):
             b = (first + s) % nb
-            t = sharded.search_begin(queries[b * BATCH:(b + 1) * BATCH], TOPK)
-            if ticket is not None:
-                last = sharded.search_end(ticket)
-            ticket = t
-        if ticket is not None:
-            last = sharded.search_end(ticket)
+            pending.append(sharded.search_begin(queries[b * BATCH:(b + 1) * BATCH], TOPK))
+            if len(pending) >= IN_FLIGHT:
+                last = sharded.search_end(pending.popleft())
+        while pending:
+            last = sharded.search_end(pending.popleft())
         return last
 
     def barrier():
@@ -179,7 +182,8 @@ def main():
         "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
                    "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH,
                    "sharding": f"rows/{world}" if world > 1 else "none",
-                   "exchange": "1 all-gather of [2,32,10] int64 per step, 1 step in flight" if world > 1 else "none"},
+                   "exchange": "1 all-gather of [2,32,10] int64 per step" if world > 1 else "none",
+                   "steps_in_flight": IN_FLIGHT},
         "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "fallback_queries": int(st["fallback_queries"]),

@@ -14,9 +14,10 @@
 // One search pass answers up to 32 queries (the N dimension of the 32x32 MFMA tile):
 //   K1  scan_kernel     every wave streams a contiguous range of blocks; queries sit in LDS in B-fragment order;
 //                       exact-fp32 MFMA (a k-ordered fmaf chain) gives a 32 rows x 32 queries score tile; the
-//                       epilogue keeps only max-over-4-rows ("group maxima") -> gmax[query][group]  (N/4 floats/query)
-//   K2a select_kernel   per (query, 4096-group chunk): exact top-(K'+1) of the group maxima
-//   K2b finish_kernel   per query: merge chunk winners -> K' best groups, re-score their 4*K' rows in fp64 from the
+//                       epilogue keeps only max-over-16-rows ("group maxima", one per lane and block) staged in LDS and
+//                       written as whole lines -> gmax[query][group]  (N/16 floats/query)
+//   K2a select_kernel   per (query, 4096-group slice): exact top-(K'+1) of the group maxima
+//   K2b finish_kernel   per query: merge slice winners -> K' best groups, re-score their 16*K' rows in fp64 from the
 //                       fp32 data, exact top-k under (score, id); then a CERTIFICATE: every row outside the K' groups
 //                       has fp32 score <= m (the (K'+1)-th group maximum), hence exact score <= m + eps, eps a
 //                       worst-case bound of the fp32 chain error.  If the k-th exact score is not > m + eps the
@@ -143,14 +144,96 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
 
 struct ScanArgs {
     const float4* xb;     // blocked index
-    const float4* qf;     // [P*64] query fragments (qprep_kernel)
+    const float4* qf;     // [P*64] query fragments (qprep_kernel; fp32 path)
+    const float* q;       // [nq, d] row-major queries (split path builds its fragments in the scan prologue)
     const float* norms;   // [rows] squared norms (L2 only)
-    float* gmax;          // [kMaxQ, gstride] group maxima
+    float* gmax;          // [kMaxQ, gstride] group maxima: one per (block, lane half) = 16 rows, chunk-permuted
     int64_t gstride;
     int64_t nblocks;
     int64_t ntotal;
     int nq, d, P;
 };
+
+// ---- group maxima -----------------------------------------------------------------------------------------------
+// A GROUP is the 16 rows one lane holds of a block's score tile: rows 32*blk + 8g + 4h + j (g, j in 0..3) for lane half
+// h.  The scan keeps only max-over-group (N/16 floats per query, 8 MB per pass at 1M x 32 queries): written per block
+// as 16 B per lane the same data costs ~15 % of the scan (32 MB of partial-line writes turning the HBM bus around), as
+// one float per lane it is nearly free.  Each wave parks its lane maxima in LDS ([16 blocks][64 lanes]) and every 16
+// blocks each lane writes its 16 values as one 64-B run, so a query's (h = 0, h = 1) pair fills a whole 128-B line:
+//   slot of (block cb + j of a chunk of cnt blocks starting at cb, half h) = 2*cb + h*cnt + j      (see group_decode)
+constexpr int kChunk = 16;
+
+__host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks, int64_t nwaves)
+{
+    const int64_t bpw = (nblocks + nwaves - 1) / nwaves;
+    return (bpw + 1) & ~(int64_t)1;  // even, so every chunk base is even and 16-value runs are 16-byte aligned
+}
+
+// slot -> (block, lane half); inverse of the permutation above.  bpw = scan_blocks_per_wave(nblocks, waves of the scan).
+__device__ __forceinline__ void group_decode(int64_t slot, int64_t bpw, int64_t nblocks, int64_t& blk, int& h)
+{
+    const int64_t bq = slot >> 1;                      // lies inside the same chunk as the group's block
+    const int64_t b0 = (bq / bpw) * bpw;
+    const int64_t cb = b0 + ((bq - b0) / kChunk) * kChunk;
+    int64_t end = b0 + bpw;
+    if (end > nblocks) end = nblocks;
+    const int64_t cnt = end - cb < kChunk ? end - cb : kChunk;
+    const int64_t off = slot - 2 * cb;
+    h = off >= cnt ? 1 : 0;
+    blk = cb + off - (h ? cnt : 0);
+}
+
+// max over this lane's 16 scores of block blk (L2: 2<x,q> - |x|^2; padded tail rows never compete)
+template <int METRIC>
+__device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (&nrm)[4], int64_t blk, int h, const ScanArgs& a)
+{
+    float sc[16];
+    if (METRIC == HIPRAG_METRIC_L2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc[4 * g + 0] = 2.f * acc[4 * g + 0] - nrm[g][0];
+            sc[4 * g + 1] = 2.f * acc[4 * g + 1] - nrm[g][1];
+            sc[4 * g + 2] = 2.f * acc[4 * g + 2] - nrm[g][2];
+            sc[4 * g + 3] = 2.f * acc[4 * g + 3] - nrm[g][3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = acc[i];
+    }
+    if ((blk + 1) * kRowsPerBlock > a.ntotal) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = blk * kRowsPerBlock + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (row >= a.ntotal) sc[i] = -INFINITY;
+        }
+    }
+    return fmaxf(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))),
+                 fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+}
+
+// Park one block's lane maximum; on the last block of a chunk (or of the wave's range) write the chunk out.
+// sw = this wave's LDS scratch [kChunk][64]; j = index of blk inside its chunk; only this wave touches sw (LDS ops of a
+// wave execute in order, so no barrier).  Plain stores: with the ring loads hidden in asm they are the only VMEM ops
+// hipcc sees here, so they never make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
+__device__ __forceinline__ void park_and_flush(float* sw, float m, int64_t blk, int64_t b0, int64_t b1, int lane,
+                                               const ScanArgs& a)
+{
+    const int j = (int)((blk - b0) % kChunk);
+    sw[j * 64 + lane] = m;
+    if (j != kChunk - 1 && blk != b1 - 1) return;
+    const int cnt = j + 1;
+    const int64_t cb = blk - j;
+    const int h = lane >> 5, qb = lane & 31;
+    float* dst = a.gmax + (int64_t)qb * a.gstride + 2 * cb + (int64_t)h * cnt;
+    if (cnt == kChunk) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            reinterpret_cast<float4*>(dst)[v] = make_float4(sw[(4 * v + 0) * 64 + lane], sw[(4 * v + 1) * 64 + lane],
+                                                            sw[(4 * v + 2) * 64 + lane], sw[(4 * v + 3) * 64 + lane]);
+    } else {
+        for (int t = 0; t < cnt; ++t) dst[t] = sw[t * 64 + lane];
+    }
+}
 
 template <int METRIC, int NWAVES, int VARIANT, int RING = 16>
 __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
@@ -166,13 +249,14 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
     // same time (a ragged last round would leave a quarter of the waves streaming alone at latency-bound rates)
     const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave;
     const int64_t W = (int64_t)gridDim.x * NWAVES;
-    const int64_t bpw = (a.nblocks + W - 1) / W;
+    const int64_t bpw = scan_blocks_per_wave(a.nblocks, W);
     const int64_t b0 = min(gw * bpw, a.nblocks);
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);  // pieces in this wave's stream
     const float4* base = a.xb + b0 * P * kPieceVec4;  // wave-uniform; lanes add 16 B each through the VGPR offset
+    float* sw = reinterpret_cast<float*>(qs + P * kPieceVec4) + wave * (kChunk * 64);  // lane-maxima scratch
     const unsigned lane16 = (unsigned)lane * 16u;
-    const int h = lane >> 5, qb = lane & 31;
+    const int h = lane >> 5;
 
     // The X stream is driven by hand: loads are inline asm (invisible to hipcc's waitcnt pass, which otherwise drains
     // the queue with vmcnt(0) at the loop back-edge) and every use is fenced by a counted s_waitcnt that takes the
@@ -231,41 +315,189 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
             }
             s += RING;
         }
-        // epilogue: acc[4g + j] = <x_row, q_qb>, row = 32*blk + 8g + 4h + j
-        float sc[16];
-        if (METRIC == HIPRAG_METRIC_L2) {
-            // the 4 norm loads were issued before this block's P >= RING ring re-arms: all but the RING youngest done
+        if (METRIC == HIPRAG_METRIC_L2)  // the 4 norm loads were issued before this block's P >= RING ring re-arms
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                sc[4 * g + 0] = 2.f * acc[4 * g + 0] - nrm[g][0];
-                sc[4 * g + 1] = 2.f * acc[4 * g + 1] - nrm[g][1];
-                sc[4 * g + 2] = 2.f * acc[4 * g + 2] - nrm[g][2];
-                sc[4 * g + 3] = 2.f * acc[4 * g + 3] - nrm[g][3];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = acc[i];
-        }
-        if ((blk + 1) * kRowsPerBlock > a.ntotal) {  // padded tail rows never compete
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t row = blk * kRowsPerBlock + 8 * (i >> 2) + 4 * h + (i & 3);
-                if (row >= a.ntotal) sc[i] = -INFINITY;
-            }
-        }
-        f32x4 o;
-        o[0] = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        o[1] = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
-        o[2] = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
-        o[3] = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
-        // group index = blk*8 + h*4 + g  <->  rows 32*blk + 8g + 4h + 0..3
-        // A plain store: with the ring loads hidden in asm it is the only VMEM op hipcc sees here, so it never
-        // makes the compiler drain the queue; in the hand-counted vmcnt it is one extra YOUNGER op (conservative).
-        float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(a.gmax + (int64_t)qb * a.gstride + blk * 8 + h * 4) = o4;
+        park_and_flush(sw, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's clamped re-arms are still in flight
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1 (bf16 hi/lo split operands).  The fp32 MFMA above keeps the matrix pipe ~75 % busy at HBM rate, so the scan is
+// co-limited.  Here every fp32 value v is split on the fly into hi = bf16(v), lo = bf16(v - hi) and a pair of pieces
+// (16 k-values) costs three v_mfma_f32_32x32x16_bf16 (hi*hi into one accumulator, hi*lo and lo*hi into a second)
+// instead of eight fp32 MFMAs: ~5x less matrix time for ~12 VALU per piece, which leaves HBM as the only limit.
+// The dropped lo*lo term and the split residues are bounded by 3.02 * 2^-18 |x_i q_i| per element; the certificate's
+// eps carries that term (finish kernels, `split` flag), so results stay exact: rows are still re-scored in fp64.
+// Query tile in LDS: for piece pair pp and lane (h, b): 8 bf16 hi parts then (second half of the tile) 8 bf16 lo parts
+// of Q[b][8(2pp) + 4h + 0..3], Q[b][8(2pp+1) + 4h + 0..3] -- the same k order the A fragment gets from two pieces.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo)
+{
+    const bf16x2 h = __builtin_convertvector(f32x2{v0, v1}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = v0 - __uint_as_float(hi << 16);
+    const float r1 = v1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void qprep_split_kernel(const float* __restrict__ q, int nq, int d, int P,
+                                                         u32x4* __restrict__ qf)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // one (pair, lane)
+    const int npairs = P / 2;
+    if (idx >= npairs * 64) return;
+    const int pp = idx >> 6, l = idx & 63;
+    const int b = l & 31, h = l >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = 8 * (2 * pp + (j >> 2)) + 4 * h + (j & 3);
+        v[j] = (b < nq && col < d) ? q[(int64_t)b * d + col] : 0.f;
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hh, ll;
+        split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+        hi[j] = hh;
+        lo[j] = ll;
+    }
+    qf[idx] = hi;
+    qf[npairs * 64 + idx] = lo;
+}
+
+template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0>
+__global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
+{
+    extern __shared__ float4 qs[];  // [P/2][64] hi fragments, then [P/2][64] lo fragments (16 B each)
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P;
+    const int npairs = P / 2;
+
+    const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave;
+    const int64_t W = (int64_t)gridDim.x * NWAVES;
+    const int64_t bpw = scan_blocks_per_wave(a.nblocks, W);
+    const int64_t b0 = min(gw * bpw, a.nblocks);
+    const int64_t b1 = min(b0 + bpw, a.nblocks);
+    const int S = (int)((b1 - b0) * P);
+    const float4* base = a.xb + b0 * P * kPieceVec4;
+    float* sw = reinterpret_cast<float*>(qs + P * kPieceVec4) + wave * (kChunk * 64);  // lane-maxima scratch
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int h = lane >> 5;
+
+    f32x4 ring[RING];
+    if (S > 0) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            const unsigned voff = lane16 + (unsigned)min(i, S - 1) * 1024u;
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
+        }
+    }
+    // Query tile: every workgroup splits the (L2-resident) row-major queries into hi/lo bf16 fragments itself -- 8 units
+    // of (pair, lane) per thread, two 16-byte reads each -- instead of a separate preparation launch: at shard sizes a
+    // kernel boundary is ~5 % of the pass.  The ring above is already streaming while this runs.
+    {
+        u32x4* qhi_w = reinterpret_cast<u32x4*>(qs);
+        u32x4* qlo_w = qhi_w + npairs * 64;
+        const bool vec_ok = (a.d & 3) == 0;
+        for (int idx = tid; idx < npairs * 64; idx += NT) {
+            const int pp = idx >> 6, l = idx & 63;
+            const int b = l & 31, hh = l >> 5;
+            float v[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int col = 8 * (2 * pp + half) + 4 * hh;
+                if (b < a.nq && vec_ok && col + 3 < a.d) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.d + col);
+                    v[4 * half + 0] = t.x; v[4 * half + 1] = t.y; v[4 * half + 2] = t.z; v[4 * half + 3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[4 * half + j] = (b < a.nq && col + j < a.d) ? a.q[(int64_t)b * a.d + col + j] : 0.f;
+                }
+            }
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split_pair(v[0], v[1], h0, l0);
+            split_pair(v[2], v[3], h1, l1);
+            split_pair(v[4], v[5], h2, l2);
+            split_pair(v[6], v[7], h3, l3);
+            qhi_w[idx] = u32x4{h0, h1, h2, h3};
+            qlo_w[idx] = u32x4{l0, l1, l2, l3};
+        }
+    }
+    __syncthreads();
+    if (S <= 0) return;
+
+    const bf16x8* qhi = reinterpret_cast<const bf16x8*>(qs);
+    const bf16x8* qlo = qhi + npairs * 64;
+    int s = 0;
+    bf16x8 bh_next = qhi[lane], bl_next = qlo[lane];
+    for (int64_t blk = b0; blk < b1; ++blk) {
+        f32x4 nrm[4];
+        if (METRIC == HIPRAG_METRIC_L2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* np = a.norms + blk * kRowsPerBlock + 8 * g + 4 * h;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nrm[g]) : "v"(np) : "memory");
+            }
+        }
+        f32x16 acc_hi, acc_lo;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_hi[i] = 0.f; acc_lo[i] = 0.f; }
+        for (int pp = 0; pp < npairs; pp += RING / 2) {
+#pragma unroll
+            for (int i = 0; i < RING / 2; ++i) {
+                // one step = two 1 KiB pieces (16 k-values per lane half): split, 3 MFMAs, re-arm both ring slots
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ring[2 * i]), "+v"(ring[2 * i + 1]) : "n"(RING - 2) : "memory");
+                const f32x4 v0 = ring[2 * i], v1 = ring[2 * i + 1];
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split_pair(v0[0], v0[1], h0, l0);
+                split_pair(v0[2], v0[3], h1, l1);
+                split_pair(v1[0], v1[1], h2, l2);
+                split_pair(v1[2], v1[3], h3, l3);
+                const u32x4 ahi = {h0, h1, h2, h3}, alo = {l0, l1, l2, l3};
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi), al = __builtin_bit_cast(bf16x8, alo);
+                const bf16x8 bh = bh_next, bl = bl_next;
+                int nx = pp + i + 1;
+                nx = nx == npairs ? 0 : nx;
+                bh_next = qhi[nx * 64 + lane];
+                bl_next = qlo[nx * 64 + lane];
+                acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc_hi, 0, 0, 0);
+                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_lo, 0, 0, 0);
+                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_lo, 0, 0, 0);
+                const unsigned voff0 = lane16 + (unsigned)min(s + RING + 2 * i, S - 1) * 1024u;
+                const unsigned voff1 = lane16 + (unsigned)min(s + RING + 2 * i + 1, S - 1) * 1024u;
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[2 * i]) : "v"(voff0), "s"(base) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[2 * i + 1]) : "v"(voff1), "s"(base) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s += RING;
+        }
+        if (METRIC == HIPRAG_METRIC_L2)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = acc_hi[i] + acc_lo[i];
+        if (VARIANT == 20) {  // timing experiment: no group-max store at all
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += acc[i];
+            if (t == 123.456f) a.gmax[0] = t;
+        } else {
+            park_and_flush(sw, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -279,21 +511,36 @@ __device__ __forceinline__ double rescore4(const float4* __restrict__ xb, int P,
     const int lane = threadIdx.x & 63;
     const int rr = lane & 3, hh = (lane >> 2) & 1, pq = lane >> 3;
     const float4* src = xb + blk * P * kPieceVec4 + hh * 32 + r0 + rr;
+    // P <= 128 (LDS limit of the scan), so a lane touches at most 16 pieces.  Loads go out in batches of 8 before their
+    // first use: a dependent-latency loop here costs an HBM round trip per piece and used to dominate the finish kernel;
+    // all 16 at once spills at the 128-VGPR budget of the 16-wave finish workgroup.
     double acc = 0.0;
-    for (int p = pq; p < P; p += 8) {
-        const float4 x = src[p * kPieceVec4];
-        const float* qq = qv + 8 * p + 4 * hh;
-        if (METRIC == HIPRAG_METRIC_IP) {
-            acc += (double)x.x * (double)qq[0];
-            acc += (double)x.y * (double)qq[1];
-            acc += (double)x.z * (double)qq[2];
-            acc += (double)x.w * (double)qq[3];
-        } else {
-            double t;
-            t = (double)x.x - (double)qq[0]; acc += t * t;
-            t = (double)x.y - (double)qq[1]; acc += t * t;
-            t = (double)x.z - (double)qq[2]; acc += t * t;
-            t = (double)x.w - (double)qq[3]; acc += t * t;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = pq + 8 * (8 * half + i);
+            x[i] = p < P ? src[p * kPieceVec4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = pq + 8 * (8 * half + i);
+            if (p < P) {
+                const float* qq = qv + 8 * p + 4 * hh;
+                if (METRIC == HIPRAG_METRIC_IP) {
+                    acc += (double)x[i].x * (double)qq[0];
+                    acc += (double)x[i].y * (double)qq[1];
+                    acc += (double)x[i].z * (double)qq[2];
+                    acc += (double)x[i].w * (double)qq[3];
+                } else {
+                    double t;
+                    t = (double)x[i].x - (double)qq[0]; acc += t * t;
+                    t = (double)x[i].y - (double)qq[1]; acc += t * t;
+                    t = (double)x[i].z - (double)qq[2]; acc += t * t;
+                    t = (double)x[i].w - (double)qq[3]; acc += t * t;
+                }
+            }
         }
     }
 #pragma unroll
@@ -314,7 +561,13 @@ struct FinishArgs {
     int* arrivals;             // [nq] exhaustive-path arrival counters, zeroed here
     unsigned long long* fallback_counter;
     int64_t ntotal, id_base, ncand;  // ncand = nchunks*K1
+    int64_t bpw, nblocks;            // to decode group slots (group_decode)
+    u64* sel;                        // [nq, 64] selected groups (fast path)
+    u64* cand_k;                     // [nq, 1024] re-scored candidates
+    i64* cand_i;
+    double* qn2;                     // [nq]
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
+    int split;                 // scan used bf16 hi/lo split operands: eps gains the truncation term
 };
 
 template <int METRIC>
@@ -377,25 +630,30 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
                                     selk, seli);
     }
 
-    // re-score the K' selected groups (4 rows each)
+    // re-score the K' selected groups (16 rows each)
     for (int j = wave; j < a.Kp; j += kSelThreads / 64) {
         const u64 gk = selk[j];
         const i64 gi = seli[j];
-        u64 key = 0;
-        i64 row = -1;
-        if (gk != 0) {
-            const int64_t blk = gi >> 3;
-            const int r0 = 8 * (int)(gi & 3) + 4 * (int)((gi >> 2) & 1);
-            const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
-            row = blk * kRowsPerBlock + r0 + (lane & 3);
-            if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u64 key = 0;
+            i64 row = -1;
+            if (gk != 0) {
+                int64_t blk;
+                int gh;
+                group_decode(gi, a.bpw, a.nblocks, blk, gh);
+                const int r0 = 8 * g + 4 * gh;
+                const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+                row = blk * kRowsPerBlock + r0 + (lane & 3);
+                if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+            }
+            if (lane < 4) { keys[j * 16 + g * 4 + lane] = key; ids[j * 16 + g * 4 + lane] = row; }
         }
-        if (lane < 4) { keys[j * 4 + lane] = key; ids[j * 4 + lane] = row; }
     }
     __syncthreads();
 
     const int64_t ob = (int64_t)q * a.k;
-    wg_topk_rounds<kSelThreads>(keys, ids, a.Kp * 4, a.k, red, [&](int r, u64 k, i64 id) {
+    wg_topk_rounds<kSelThreads>(keys, ids, a.Kp * 16, a.k, red, [&](int r, u64 k, i64 id) {
         write_result<METRIC>(a.out64, a.out32, a.out_ids, ob + r, k, id, a.id_base);
         if (r == a.k - 1) kth_key = k;
     });
@@ -409,7 +667,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
                 const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
                 const double qn = sqrt(qn2);
                 const double u = 5.9604644775390625e-08;  // 2^-24
-                double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
+                double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split ? 1.52587890625e-05 : 0.0)) * qn * xn;
                 double kth_sel;  // k-th exact score on the scale the scan selects by
                 if (METRIC == HIPRAG_METRIC_IP) {
                     kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
@@ -428,41 +686,39 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K2b (fast form, K' + 1 <= 64, i.e. k <= 57): the same stages as finish_kernel, but every selection runs on the
-// wave-resident sorted lists of topk_device.h instead of barrier-per-round argmax.  One workgroup of 16 waves per
-// query: (1) each wave reduces 1/16 of select_wave_kernel's winners to its own top-K1, wave 0 merges the 16 lists;
-// (2) the K' selected groups are re-scored in fp64, one group per wave at a time; (3) wave 0 picks the final top-k
-// of the 4*K' exact scores and evaluates the certificate.  NPL = candidates per lane in stage (1).
+// K2b (fast form, K' + 1 <= 64, i.e. k <= 57): the same stages as finish_kernel on the wave-resident sorted lists of
+// topk_device.h instead of barrier-per-round argmax, split into three small launches so that every stage gets the
+// parallelism and register budget it wants (one monolithic 16-wave kernel spilled and serialised its HBM round trips):
+//   fin_merge_kernel    one 16-wave workgroup per query: each wave reduces 1/16 of select_wave_kernel's winners, wave 0
+//                       merges the 16 lists -> sel[q][0..K'] (packed value|slot), plus the query's exact |q|^2
+//   fin_rescore_kernel  one wave per (query, group, row quad): fp64 re-score straight from the blocked layout, all of a
+//                       lane's loads in flight at once -> cand[q][16 * K']
+//   fin_final_kernel    one wave per query: exact top-k of the candidates under (score, id), certificate, flags
+// All three fit beside a resident scan workgroup (<= 10 KiB LDS).
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFinWaves = 16;
-template <int METRIC, int NPL>
-__global__ __launch_bounds__(kFinWaves * 64) void finish_wave_kernel(FinishArgs a)
+constexpr int kCandPerQuery = 1024;  // 64 group slots x 16 rows
+
+template <int NPL>
+__global__ __launch_bounds__(kFinWaves * 64) void fin_merge_kernel(FinishArgs a)
 {
-    extern __shared__ unsigned char smem[];
-    u64* selk = reinterpret_cast<u64*>(smem);            // [64] packed winners (group maxima)
-    u64* lists = selk + 64;                              // [kFinWaves * 64] per-wave lists of stage (1)
-    u64* candk = lists + kFinWaves * 64;                 // [256] fp64 keys of re-scored rows
-    i64* candi = reinterpret_cast<i64*>(candk + 256);    // [256] row ids
-    double* dred = reinterpret_cast<double*>(candi + 256);
-    float* qv = reinterpret_cast<float*>(dred + kFinWaves);
+    __shared__ u64 lists[kFinWaves * 64];
+    __shared__ double dred[kFinWaves];
     constexpr int NT = kFinWaves * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;
-    const int dpad = a.P * 8;
     const int K1 = a.Kp + 1;
 
     double qpart = 0.0;
-    for (int c = tid; c < dpad; c += NT) {
-        float v = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
-        qv[c] = v;
-        qpart += (double)v * (double)v;
+    for (int c = tid; c < a.d; c += NT) {
+        const double v = (double)a.q[(int64_t)q * a.d + c];
+        qpart += v * v;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
     if (lane == 0) dred[wave] = qpart;
-
-    {   // stage (1a): this wave's share of the candidates
+    {
         const u64* sk = a.ck + (int64_t)q * a.ncand;
         const i64* si = a.ci + (int64_t)q * a.ncand;
         u64 c[NPL];
@@ -480,76 +736,110 @@ __global__ __launch_bounds__(kFinWaves * 64) void finish_wave_kernel(FinishArgs 
         lists[wave * 64 + lane] = lane < K1 ? L.e : 0;
     }
     __syncthreads();
-    if (wave == 0) {  // stage (1b): merge the 16 lists
+    if (wave == 0) {
         u64 c[kFinWaves];
 #pragma unroll
         for (int n = 0; n < kFinWaves; ++n) c[n] = lists[n * 64 + lane];
         WaveListPacked L;
         wave_topk_packed<kFinWaves>(c, K1, L);
-        selk[lane] = L.e;
-    }
-    __syncthreads();
-    double qn2 = 0.0;
-    for (int w = 0; w < kFinWaves; ++w) qn2 += dred[w];
-
-    for (int j = wave; j < 64; j += kFinWaves) {   // 64 slots x 4 rows = the 256 candidate entries
-        u64 key = 0;
-        i64 row = -1;
-        if (j < a.Kp) {
-            const u64 e = selk[j];
-            if (e != 0) {
-                const i64 gi = (i64)packed_index(e);
-                const int64_t blk = gi >> 3;
-                const int r0 = 8 * (int)(gi & 3) + 4 * (int)((gi >> 2) & 1);
-                const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
-                row = blk * kRowsPerBlock + r0 + (lane & 3);
-                if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
-            }
-        }
-        if (lane < 4) { candk[j * 4 + lane] = key; candi[j * 4 + lane] = row; }
-    }
-    __syncthreads();
-
-    if (wave == 0) {  // stage (3)
-        u64 ck4[4];
-        i64 ci4[4];
-        u64 m = 0;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            ck4[n] = candk[n * 64 + lane];
-            ci4[n] = candi[n * 64 + lane];
-            m = ck4[n] > m ? ck4[n] : m;
-        }
-        const u64 t0 = wave_kth_of_lanes(m, a.k);   // k lanes hold a key >= t0: nothing below t0 can reach the top k
-        WaveListPair F;
-        F.init();
-#pragma unroll
-        for (int n = 0; n < 4; ++n) F.offer(ck4[n] >= t0 ? ck4[n] : 0ull, ci4[n], a.k);
-        if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
-        const u64 kth_key = readlane_u64(F.k, a.k - 1);
+        a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L.e : 0;
         if (lane == 0) {
-            int flag = 0;
-            const u64 bk = selk[a.Kp];  // best group NOT re-scored
-            if (bk != 0) {
-                const float m32 = packed_value(bk);
-                const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
-                const double qn = sqrt(qn2);
-                const double u = 5.9604644775390625e-08;  // 2^-24
-                double eps = 1.05 * (double)(dpad + 2) * u * qn * xn;
-                double kth_sel;
-                if (METRIC == HIPRAG_METRIC_IP) {
-                    kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
-                } else {
-                    eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
-                    kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
-                    eps += 4.0 * u * qn2;
-                }
-                if (!(kth_sel > (double)m32 + eps)) flag = 1;
-            }
-            a.flags[q] = flag;
-            a.arrivals[q] = 0;
-            if (flag) atomicAdd(a.fallback_counter, 1ull);
+            double qn2 = 0.0;
+            for (int w = 0; w < kFinWaves; ++w) qn2 += dred[w];
+            a.qn2[q] = qn2;
         }
+    }
+}
+
+// grid (K', nq), 256 threads: wave g of workgroup (j, q) re-scores rows 8g + 4h + 0..3 of selected group j
+template <int METRIC>
+__global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
+{
+    extern __shared__ float qv[];  // d_pad floats
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int j = blockIdx.x, q = blockIdx.y;
+    const int dpad = a.P * 8;
+    for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+    __syncthreads();
+    const u64 e = a.sel[(int64_t)q * 64 + j];
+    u64 key = 0;
+    i64 row = -1;
+    if (e != 0) {
+        int64_t blk;
+        int gh;
+        group_decode((i64)packed_index(e), a.bpw, a.nblocks, blk, gh);
+        const int r0 = 8 * g + 4 * gh;
+        const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+        row = blk * kRowsPerBlock + r0 + (lane & 3);
+        if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+    }
+    if (lane < 4) {
+        const int64_t o = (int64_t)q * kCandPerQuery + j * 16 + g * 4 + lane;
+        a.cand_k[o] = key;
+        a.cand_i[o] = row;
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int ncand = a.Kp * 16;
+    const u64* ck = a.cand_k + (int64_t)q * kCandPerQuery;
+    const i64* ci = a.cand_i + (int64_t)q * kCandPerQuery;
+    u64 ckc[16];
+    i64 cic[16];
+    u64 m = 0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = n * 64 + lane;
+        ckc[n] = i < ncand ? ck[i] : 0ull;
+        cic[n] = i < ncand ? ci[i] : -1;
+        m = ckc[n] > m ? ckc[n] : m;
+    }
+    const u64 t0 = wave_kth_of_lanes(m, a.k);   // k lanes hold a key >= t0: nothing below t0 can reach the top k
+    WaveListPair F;
+    F.init();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) F.offer(ckc[n] >= t0 ? ckc[n] : 0ull, cic[n], a.k);
+    if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
+    const u64 kth_key = readlane_u64(F.k, a.k - 1);
+    if (lane == 0) {
+        int flag = 0;
+        const u64 bk = a.sel[(int64_t)q * 64 + a.Kp];  // best group NOT re-scored
+        if (bk != 0) {
+            const float m32 = packed_value(bk);
+            const double qn2 = a.qn2[q];
+            const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
+            const double qn = sqrt(qn2);
+            const double u = 5.9604644775390625e-08;  // 2^-24
+            const int dpad = a.P * 8;
+            double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split ? 1.52587890625e-05 : 0.0)) * qn * xn;
+            double kth_sel;
+            if (METRIC == HIPRAG_METRIC_IP) {
+                kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
+            } else {
+                eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
+                kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
+                eps += 4.0 * u * qn2;
+            }
+            if (!(kth_sel > (double)m32 + eps)) flag = 1;
+        }
+        a.flags[q] = flag;
+        a.arrivals[q] = 0;
+        if (flag) atomicAdd(a.fallback_counter, 1ull);
+    }
+}
+
+// For k beyond what the selection kernels hold (K' * 16 re-scored rows > 4096) every query goes straight to the exhaustive
+// path: exact, just not fast -- k in the hundreds is outside anything the reference asks for (top_chunks = 50).
+__global__ void flag_all_kernel(int* flags, int* arrivals, unsigned long long* fallback_counter, int nq)
+{
+    const int q = threadIdx.x;
+    if (q < nq) {
+        flags[q] = 1;
+        arrivals[q] = 0;
+        atomicAdd(fallback_counter, 1ull);
     }
 }
 
@@ -586,51 +876,56 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_kernel(ExArgs a)
     int* ticket = reinterpret_cast<int*>(qv + a.P * 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dpad = a.P * 8;
-    const int64_t row_base = (int64_t)blockIdx.x * kExRows;
-    const int nrows = (int)min((int64_t)kExRows, a.ntotal - row_base);
-    for (int q = 0; q < a.nq; ++q) {
-        if (!a.flags[q]) continue;  // uniform across the workgroup; the common case touches nothing else
-        __syncthreads();
-        for (int c = tid; c < dpad; c += kSelThreads) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
-        __syncthreads();
-        for (int g = wave; g * 4 < kExRows; g += kSelThreads / 64) {
-            const int64_t row0 = row_base + (int64_t)g * 4;
-            u64 key = 0;
-            const int64_t row = row0 + (lane & 3);
-            if (row0 < a.ntotal) {
-                const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
-                if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+    bool any = false;
+    for (int q = 0; q < a.nq; ++q) any = any || a.flags[q] != 0;
+    if (!any) return;  // the common case: a <= n_cu-workgroup launch that reads nq flags and leaves
+    for (int slice = blockIdx.x; slice < a.nslices; slice += gridDim.x) {
+        const int64_t row_base = (int64_t)slice * kExRows;
+        const int nrows = (int)min((int64_t)kExRows, a.ntotal - row_base);
+        for (int q = 0; q < a.nq; ++q) {
+            if (!a.flags[q]) continue;  // uniform across the workgroup
+            __syncthreads();
+            for (int c = tid; c < dpad; c += kSelThreads) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+            __syncthreads();
+            for (int g = wave; g * 4 < kExRows; g += kSelThreads / 64) {
+                const int64_t row0 = row_base + (int64_t)g * 4;
+                u64 key = 0;
+                const int64_t row = row0 + (lane & 3);
+                if (row0 < a.ntotal) {
+                    const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
+                    if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+                }
+                if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
             }
-            if (lane < 4) { keys[g * 4 + lane] = key; ids[g * 4 + lane] = row; }
-        }
-        __syncthreads();
-        const int64_t M = (int64_t)a.nslices * a.kk;
-        u64* ok = a.ek + (int64_t)q * M + (int64_t)blockIdx.x * a.kk;
-        i64* oi = a.ei + (int64_t)q * M + (int64_t)blockIdx.x * a.kk;
-        wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
-        // Publish this slice, then take a ticket (cdna_hip_programming.md Guideline 16, counter form): stores drained by
-        // their wave -> workgroup barrier -> one lane: agent-scope release, explicit drain, relaxed agent atomic.  The
-        // last arriver acquires once, and the barrier after it holds every wave's loads behind the invalidate.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            const int64_t M = (int64_t)a.nslices * a.kk;
+            u64* ok = a.ek + (int64_t)q * M + (int64_t)slice * a.kk;
+            i64* oi = a.ei + (int64_t)q * M + (int64_t)slice * a.kk;
+            wg_topk_rounds<kSelThreads>(keys, ids, max(nrows, 0), a.kk, red, [&](int r, u64 k, i64 id) { ok[r] = k; oi[r] = id; });
+            // Publish this slice, then take a ticket (cdna_hip_programming.md Guideline 16, counter form): stores drained
+            // by their wave -> workgroup barrier -> one lane: agent-scope release, explicit drain, relaxed agent atomic.
+            // The last arriver acquires once, and the barrier after it holds every wave's loads behind the invalidate.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int t = __hip_atomic_fetch_add(a.arrivals + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == a.nslices - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int t = __hip_atomic_fetch_add(a.arrivals + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == a.nslices - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *ticket = t;
             }
-            *ticket = t;
-        }
-        __syncthreads();
-        if (*ticket == a.nslices - 1) {  // last arriver merges
-            const u64* sk = a.ek + (int64_t)q * M;
-            const i64* si = a.ei + (int64_t)q * M;
-            wg_stream_topk<kSelThreads, kExRows>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, M, a.k, keys, ids,
-                                                 red, selk, seli);
-            for (int r = tid; r < a.k; r += kSelThreads)
-                write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + r, selk[r], seli[r], a.id_base);
+            __syncthreads();
+            if (*ticket == a.nslices - 1) {  // last arriver merges
+                const u64* sk = a.ek + (int64_t)q * M;
+                const i64* si = a.ei + (int64_t)q * M;
+                wg_stream_topk<kSelThreads, kExRows>([&](i64 i, u64& k, i64& id) { k = sk[i]; id = si[i]; }, M, a.k, keys, ids,
+                                                     red, selk, seli);
+                for (int r = tid; r < a.k; r += kSelThreads)
+                    write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + r, selk[r], seli[r], a.id_base);
+            }
         }
     }
 }
@@ -638,16 +933,31 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_kernel(ExArgs a)
 // ------------------------------------------------------------------------------------------------------
 // host object
 // ------------------------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, size) instead of on every launch
+static int32_t ensure_lds(const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find(fn);
+    if (it != done.end() && it->second >= bytes) return HIPRAG_OK;
+    HR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[fn] = bytes;
+    return HIPRAG_OK;
+}
+
 struct DenseIndex {
     std::mutex mu;
     int device = 0;
     int d = 0, P = 0, metric = 0;
     int64_t ntotal = 0, cap_blocks = 0, id_base = 0;
     int n_cu = 256;
+    bool split_mode = true;   // HIPRAG_SCAN_MODE=f32 selects the exact-fp32 MFMA scan (read once, at creation)
+    int scan_variant = 0;     // HIPRAG_SCAN_VARIANT: timing experiments only
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei; };
-    static constexpr int kSlots = 2;   // two passes may be in flight (scan of pass i+1 beside the finish of pass i)
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0; };
+    static constexpr int kSlots = 4;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
     int ws_k = 0;
@@ -675,6 +985,10 @@ struct DenseIndex {
         hipDeviceProp_t prop;
         HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const char* ms = getenv("HIPRAG_SCAN_MODE");
+        split_mode = !(ms && ms[0] == 'f');
+        const char* vs = getenv("HIPRAG_SCAN_VARIANT");
+        scan_variant = vs ? atoi(vs) : 0;
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
@@ -751,7 +1065,7 @@ struct DenseIndex {
         if (k <= ws_k && nb <= ws_blocks) return HIPRAG_OK;
         const int kk = std::max(k, ws_k);
         const int64_t nbb = std::max(nb, ws_blocks);
-        const int64_t gstride = nbb * 8;
+        const int64_t gstride = ((2 * nbb + 3) / 4) * 4;
         const int64_t nchunks = (gstride + kSelChunk - 1) / kSelChunk;
         const int K1 = kprime(kk) + 1;
         const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
@@ -764,6 +1078,8 @@ struct DenseIndex {
             if ((rc = w.ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
             if ((rc = w.ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
             if ((rc = w.flags.reserve(2 * kMaxQ * sizeof(int)))) return rc;  // flags[kMaxQ] + arrivals[kMaxQ]
+            // sel[kMaxQ][64] u64 | cand_k[kMaxQ][1024] u64 | cand_i[kMaxQ][1024] i64 | qn2[kMaxQ] f64
+            if ((rc = w.fin.reserve((size_t)kMaxQ * (64 + 2 * kCandPerQuery + 1) * 8))) return rc;
             if ((rc = w.ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
             if ((rc = w.ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
         }
@@ -779,23 +1095,32 @@ struct DenseIndex {
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
         ScanArgs sa;
-        sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
-        sa.gstride = ws_blocks * 8; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
-        const char* vs = getenv("HIPRAG_SCAN_VARIANT");  // timing experiments only (variants 1 and 6 give wrong scores)
-        const int variant = vs ? atoi(vs) : 0;
-        int NW = 8;
-        void (*scan)(ScanArgs) = scan_kernel<METRIC, 8, 0>;
-        if (variant == 1) scan = scan_kernel<METRIC, 8, 1>;
-        if (variant == 2) { scan = scan_kernel<METRIC, 16, 0>; NW = 16; }
-        if (variant == 6) scan = scan_kernel<METRIC, 8, 6>;
-        const size_t scan_lds = (size_t)P * 1024;
-        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)scan_lds));
-        hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
-                           w.qf.as<float4>());
+        sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
+        sa.gstride = ((2 * ws_blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
+        // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
+        const bool split = split_mode;
+        w.split = split ? 1 : 0;
+        const size_t scan_lds = (size_t)P * 1024 + 8 * kChunk * 64 * sizeof(float);  // query tile + lane-maxima scratch
         const int ev = (int)(ev_count % kEvRing);
-        if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
-        if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
+        if (split) {
+            void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
+            const char* vs = getenv("HIPRAG_SCAN_VARIANT");  // timing experiments only
+            if (vs && atoi(vs) == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;
+            { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
+            if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
+            if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(8 * 64), scan_lds, st, sa);
+        } else {
+            const int variant = scan_variant;  // timing experiments only (variants 1 and 6 give wrong scores)
+            int NW = 8;
+            void (*scan)(ScanArgs) = scan_kernel<METRIC, 8, 0>;
+            if (variant == 1) scan = scan_kernel<METRIC, 8, 1>;
+            if (variant == 6) scan = scan_kernel<METRIC, 8, 6>;
+            { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
+            hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
+                               w.qf.as<float4>());
+            if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
+            if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
+        }
         if (timing) { HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st)); ++ev_count; }
         HR_CHECK_HIP(hipGetLastError());
         ++passes;
@@ -809,8 +1134,8 @@ struct DenseIndex {
     {
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
-        const int64_t gstride = ws_blocks * 8;
-        const int64_t ngroups = nb * 8;
+        const int64_t gstride = ((2 * ws_blocks + 3) / 4) * 4;
+        const int64_t ngroups = nb * 2;
         const int Kp = kprime(k), K1 = Kp + 1;
         const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
         int* flags = w.flags.as<int>();
@@ -820,7 +1145,8 @@ struct DenseIndex {
         fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = w.ck.as<u64>(); fa.ci = w.ci.as<i64>();
         fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
         fa.flags = flags; fa.arrivals = arrivals; fa.fallback_counter = fallback_counter();
-        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp;
+        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp; fa.split = w.split;
+        fa.nblocks = nb; fa.bpw = scan_blocks_per_wave(nb, (int64_t)n_cu * 8);
         const int64_t sel_waves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
         const int64_t sel_slices = (sel_waves + 3) / 4;
         const int64_t wave_cand = sel_slices * 4 * K1;
@@ -829,17 +1155,22 @@ struct DenseIndex {
             hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)sel_slices, nq), dim3(256), 0, st,
                                (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
             fa.ncand = wave_cand;
-            const size_t fin_lds = (64 + kFinWaves * 64 + 256) * 8 + 256 * 8 + kFinWaves * sizeof(double) +
-                                   (size_t)P * 8 * sizeof(float);
+            u64* fin_base = w.fin.as<u64>();
+            fa.sel = fin_base;
+            fa.cand_k = fin_base + (size_t)kMaxQ * 64;
+            fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)kMaxQ * kCandPerQuery);
+            fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)kMaxQ * kCandPerQuery);
             const int64_t per_lane = (wave_cand + kFinWaves * 64 - 1) / (kFinWaves * 64);
-            void (*fin)(FinishArgs) = finish_wave_kernel<METRIC, 16>;
-            if (per_lane <= 1) fin = finish_wave_kernel<METRIC, 1>;
-            else if (per_lane <= 2) fin = finish_wave_kernel<METRIC, 2>;
-            else if (per_lane <= 4) fin = finish_wave_kernel<METRIC, 4>;
-            else if (per_lane <= 8) fin = finish_wave_kernel<METRIC, 8>;
-            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)fin_lds));
-            hipLaunchKernelGGL(fin, dim3(nq), dim3(kFinWaves * 64), fin_lds, st, fa);
+            void (*mrg)(FinishArgs) = fin_merge_kernel<16>;
+            if (per_lane <= 1) mrg = fin_merge_kernel<1>;
+            else if (per_lane <= 2) mrg = fin_merge_kernel<2>;
+            else if (per_lane <= 4) mrg = fin_merge_kernel<4>;
+            else if (per_lane <= 8) mrg = fin_merge_kernel<8>;
+            hipLaunchKernelGGL(mrg, dim3(nq), dim3(kFinWaves * 64), 0, st, fa);
+            hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3(Kp, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
+            hipLaunchKernelGGL(fin_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, fa);
+        } else if ((int64_t)Kp * 16 > kSelChunk) {
+            hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(64), 0, st, flags, arrivals, fallback_counter(), nq);
         } else {
             hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
                                (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
@@ -847,8 +1178,7 @@ struct DenseIndex {
             const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
                                    (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
             auto fin = finish_kernel<METRIC>;
-            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fin), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)fin_lds));
+            { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(fin), fin_lds); if (lrc) return lrc; }
             hipLaunchKernelGGL(fin, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);
         }
 
@@ -861,9 +1191,8 @@ struct DenseIndex {
         const size_t ex_lds = (size_t)kExRows * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
                               (size_t)P * 8 * sizeof(float) + 16;
         auto exk = exhaustive_kernel<METRIC>;
-        HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(exk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)ex_lds));
-        hipLaunchKernelGGL(exk, dim3(ea.nslices), dim3(kSelThreads), ex_lds, st, ea);
+        { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(exk), ex_lds); if (lrc) return lrc; }
+        hipLaunchKernelGGL(exk, dim3(std::min(ea.nslices, n_cu)), dim3(kSelThreads), ex_lds, st, ea);
         HR_CHECK_HIP(hipGetLastError());
         return HIPRAG_OK;
     }
@@ -932,8 +1261,8 @@ int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_h
     HR_REQUIRE(d > 0, "d must be positive (got %d)", d);
     HR_REQUIRE(metric == HIPRAG_METRIC_IP || metric == HIPRAG_METRIC_L2, "unknown metric %d", metric);
     const int P = ((d + 127) / 128) * 16;
-    if ((size_t)P * 1024 > 160 * 1024 - 1024) {
-        set_error("d=%d needs %d KiB of LDS for the query tile; the scan supports d <= 1152", d, P);
+    if ((size_t)P * 1024 + 8 * 16 * 64 * 4 > 160 * 1024) {
+        set_error("d=%d needs %d KiB of LDS for the query tile (+32 KiB scratch); the scan supports d <= 1024", d, P);
         return HIPRAG_E_UNSUPPORTED;
     }
     auto ix = std::make_shared<DenseIndex>();
@@ -1028,7 +1357,7 @@ int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int3
     GET_INDEX(h);
     HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_begin takes 1..%d queries (got %d)", kMaxQ, nq);
     HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
-    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be 0 or 1");
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..3");
     HR_REQUIRE(q_dev, "null device pointer");
     int32_t rc = ix->prepare(k);
     if (rc) return rc;
@@ -1041,7 +1370,7 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
     GET_INDEX(h);
     HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_finish takes 1..%d queries (got %d)", kMaxQ, nq);
     HR_REQUIRE(k > 0 && k <= ix->ws_k, "k=%d was not prepared by search_begin", k);
-    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be 0 or 1");
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..3");
     HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
     return ix->finish_dev(q_dev, nq, k, slot, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
 }

@@ -104,15 +104,18 @@ class HipFlatIndex:
                  _stream_ptr())
         return s64, s32, ids
 
-    def search_begin(self, q, k: int, slot: int = 0) -> None:
-        """Phase 1 of a pass (<= 32 queries): enqueue query fragments + the index scan into workspace `slot`."""
-        nat.call("hipidx_search_begin_dev", self._h, q.data_ptr(), q.shape[0], int(k), int(slot), _stream_ptr())
+    def search_begin(self, q, k: int, slot: int = 0, stream: Optional[int] = None) -> None:
+        """Phase 1 of a pass (<= 32 queries): enqueue query fragments + the index scan into workspace `slot`.
+        `stream` = raw hipStream_t (int) or None for torch's current stream."""
+        nat.call("hipidx_search_begin_dev", self._h, q.data_ptr(), q.shape[0], int(k), int(slot),
+                 _stream_ptr() if stream is None else ctypes.c_void_p(stream))
 
-    def search_finish(self, q, k: int, slot: int, out):
+    def search_finish(self, q, k: int, slot: int, out, stream: Optional[int] = None):
         """Phase 2: selection, fp64 re-score, top-k, certificate; `out` = (scores64, scores32, ids) CUDA tensors."""
         s64, s32, ids = out
         nat.call("hipidx_search_finish_dev", self._h, q.data_ptr(), q.shape[0], int(k), int(slot), s64.data_ptr(),
-                 s32.data_ptr() if s32 is not None else None, ids.data_ptr(), _stream_ptr())
+                 s32.data_ptr() if s32 is not None else None, ids.data_ptr(),
+                 _stream_ptr() if stream is None else ctypes.c_void_p(stream))
         return out
 
     def reserve_search(self, k: int) -> None:

@@ -19,6 +19,7 @@ from typing import List, Tuple
 from .index import HipFlatIndex, merge_topk_device
 
 MAX_PASS = 32   # queries per scan pass (the N dimension of the MFMA tile)
+N_SLOTS = 4     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
 
 
 def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
@@ -52,59 +53,77 @@ class ShardedFlatIndex:
         local.set_id_base(row_lo)
         # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
         # the tail of batch i+1, which cannot start before scan i+1 ends
-        self.side = [torch.cuda.Stream(device=local.device), torch.cuda.Stream(device=local.device)]
+        self.side = [torch.cuda.Stream(device=local.device) for _ in range(N_SLOTS)]
+        self._side_ptr = [st.cuda_stream for st in self.side]
         self._slot = 0
-        self._slot_done = [None, None]
+        self._slot_used = [False] * N_SLOTS
+        self._slot_ended = [False] * N_SLOTS
+        self._bufs = [dict() for _ in range(N_SLOTS)]
+
+    def _buffers(self, slot: int, nq: int, k: int, dev):
+        """Per-slot result buffers and events, created once per (nq, k): the steady state allocates nothing."""
+        import torch
+        key = (nq, k)
+        cache = self._bufs[slot]
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+            cache["pack"] = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
+            cache["s32"] = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            cache["gathered"] = (torch.empty((self.world, 2, nq, k), dtype=torch.int64, device=dev)
+                                 if self.world > 1 else None)
+            cache["merged"] = ((torch.empty((nq, k), dtype=torch.float64, device=dev),
+                                torch.empty((nq, k), dtype=torch.float32, device=dev),
+                                torch.empty((nq, k), dtype=torch.int64, device=dev)) if self.world > 1 else None)
+            cache["scanned"], cache["done"], cache["fin"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        return cache
 
     def search_begin(self, q, k: int):
-        """q: float32 CUDA tensor [nq <= 32, d] that stays valid until search_end.  Returns a ticket."""
+        """q: float32 CUDA tensor [nq <= 32, d] that stays valid until search_end.  Returns a ticket.  The result
+        tensors handed out by search_end belong to the slot and are reused N_SLOTS passes later."""
         import torch
-        import torch.distributed as dist
         nq = q.shape[0]
         if nq > MAX_PASS:
             raise ValueError(f"search_begin takes at most {MAX_PASS} queries; use search_device for larger batches")
-        slot, self._slot = self._slot, self._slot ^ 1
+        slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
-        if self._slot_done[slot] is not None:
-            main.wait_event(self._slot_done[slot])      # the pass that last used this workspace slot has finished
-        pack = torch.empty((2, nq, k), dtype=torch.int64, device=q.device)
-        s32 = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-        gathered = (torch.empty((self.world, 2, nq, k), dtype=torch.int64, device=q.device) if self.world > 1 else None)
+        c = self._buffers(slot, nq, k, q.device)
+        if self._slot_used[slot] and not self._slot_ended[slot]:
+            # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
+            # waited there and stream order covers it (one barrier packet less per step)
+            main.wait_event(c["fin"] if self.world > 1 else c["done"])
+        self._slot_used[slot] = True
+        self._slot_ended[slot] = False
         side = self.side[slot]
-        for t in (pack, s32, gathered):
-            if t is not None:
-                t.record_stream(side)
-        self.local.search_begin(q, k, slot)
-        scanned = torch.cuda.Event()
-        scanned.record(main)
+        pack = c["pack"]
+        self.local.search_begin(q, k, slot, stream=main.cuda_stream)
+        c["scanned"].record(main)
+        side.wait_event(c["scanned"])
+        self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=self._side_ptr[slot])
+        c["done"].record(side)
         work = None
-        with torch.cuda.stream(side):
-            side.wait_event(scanned)
-            self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), s32, pack[1]))
-            done = torch.cuda.Event()
-            done.record(side)
-            self._slot_done[slot] = done
-            if self.world > 1:
-                work = all_gather_packed(pack, gathered, self.group, async_op=True)
-        return (work, pack, s32, gathered, k, slot, done)
+        if self.world > 1:
+            with torch.cuda.stream(side):
+                work = all_gather_packed(pack, c["gathered"], self.group, async_op=True)
+        return (work, slot, k)
 
     def search_end(self, ticket):
         """-> (scores64, scores32, ids) [nq,k]; the caller's current stream is made to wait for them."""
         import torch
-        work, pack, s32, gathered, k, slot, done = ticket
+        work, slot, k = ticket
+        c = self._bufs[slot]
         main = torch.cuda.current_stream()
+        self._slot_ended[slot] = True
         if work is None:
-            main.wait_event(done)
-            return (pack[0].view(torch.float64), s32, pack[1])
+            main.wait_event(c["done"])
+            return (c["pack"][0].view(torch.float64), c["s32"], c["pack"][1])
         side = self.side[slot]
         with torch.cuda.stream(side):
             work.wait()              # side stream waits for the collective; the host does not block
-            out = merge_topk_device(gathered[:, 0].view(torch.float64), gathered[:, 1], k, self.local.metric)
-            fin = torch.cuda.Event()
-            fin.record(side)
-        for t in out:
-            t.record_stream(main)
-        main.wait_event(fin)
+            g = c["gathered"]
+            out = merge_topk_device(g[:, 0].view(torch.float64), g[:, 1], k, self.local.metric, out=c["merged"])
+            c["fin"].record(side)
+        main.wait_event(c["fin"])
         return out
 
     def search_device(self, q, k: int):
@@ -113,14 +132,24 @@ class ShardedFlatIndex:
         nq = q.shape[0]
         if nq <= MAX_PASS:
             return self.search_end(self.search_begin(q, k))
-        outs, ticket = [], None
+        out = (torch.empty((nq, k), dtype=torch.float64, device=q.device),
+               torch.empty((nq, k), dtype=torch.float32, device=q.device),
+               torch.empty((nq, k), dtype=torch.int64, device=q.device))
+        pending = []
+
+        def drain():
+            o, t = pending.pop(0)
+            res = self.search_end(t)          # slot-owned buffers: copy out before the slot is reused
+            for dst, src in zip(out, res):
+                dst[o:o + src.shape[0]].copy_(src)
+
         for o in range(0, nq, MAX_PASS):
-            t = self.search_begin(q[o:o + MAX_PASS], k)
-            if ticket is not None:
-                outs.append(self.search_end(ticket))
-            ticket = t
-        outs.append(self.search_end(ticket))
-        return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(3))
+            pending.append((o, self.search_begin(q[o:o + MAX_PASS], k)))
+            if len(pending) >= N_SLOTS - 1:
+                drain()
+        while pending:
+            drain()
+        return out
 
 
 class EmulatedShards:

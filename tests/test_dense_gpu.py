@@ -202,9 +202,9 @@ def test_two_stream_pipeline_matches_oracle(gpu):
     for o in range(0, q.shape[0], 32):
         t = sh.search_begin(qd[o:o + 32], k)
         if tickets is not None:
-            outs.append(sh.search_end(tickets))
+            outs.append(tuple(x.clone() for x in sh.search_end(tickets)))   # results live in slot-owned buffers
         tickets = t
-    outs.append(sh.search_end(tickets))
+    outs.append(tuple(x.clone() for x in sh.search_end(tickets)))
     torch.cuda.synchronize()
     ids = torch.cat([o[2] for o in outs]).cpu().numpy()
     s32 = torch.cat([o[1] for o in outs]).cpu().numpy()
