@@ -213,6 +213,14 @@ def main():
                                          f"fp32 C restatement of IndexFlat search (FAISS itself is not installed)",
                                "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
                                "ids_equal_gpu": agree}
+    # HBM traffic of the scan kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside this
+    # process); the committed summary applies to the full-size single-GPU workload only.
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_scan.json")
+    if world == 1 and n_rows == N_ROWS and os.path.exists(pmc):
+        with open(pmc) as f:
+            p = json.load(f)
+        out["roofline"]["traffic"] = int(p["traffic_bytes_per_launch"])
+        out["roofline"]["traffic_source"] = "profiles/r01_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     print(json.dumps(out))
     if world > 1:
         dist.barrier()
