@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
     const SlotRange r = ranges[b];
     const u64 start = r.lo + (u64)blockIdx.x * kTaatChunk;
     if (start >= r.hi) return;
-    float* accb = acc + (i64)b * n_docs;
+    float* accb = acc + (i64)b * n_docs;  // n_docs here is the padded row stride
     // strided by thread so that each load instruction is a contiguous 1 KiB (u32/f32 x 256 threads)
 #pragma unroll
     for (int j = 0; j < kTaatPerThread; ++j) {
@@ -92,14 +92,17 @@ struct Bm25Index {
     i64 queries = 0, postings_touched = 0, bytes_alg = 0;
 
     i64 nchunks() const { return std::max<i64>(1, (n_docs + kTile - 1) / kTile); }
+    i64 stride() const { return std::max<i64>(4, (n_docs + 3) / 4 * 4); }       // accumulator row stride (16-B aligned rows)
+    i64 nlists() const { return (std::max<i64>(1, (n_docs + kSelPerWave - 1) / kSelPerWave) + 3) / 4 * 4; }
 
     int32_t reserve(int k)
     {
         int32_t rc;
-        if ((rc = acc.reserve((size_t)kBatch * std::max<i64>(n_docs, 1) * sizeof(float)))) return rc;
+        if ((rc = acc.reserve((size_t)kBatch * stride() * sizeof(float)))) return rc;
         if (k > ws_k) {
-            if ((rc = ck.reserve((size_t)kBatch * nchunks() * k * sizeof(u64)))) return rc;
-            if ((rc = ci.reserve((size_t)kBatch * nchunks() * k * sizeof(i64)))) return rc;
+            const i64 per_q = std::max(nchunks(), nlists());
+            if ((rc = ck.reserve((size_t)kBatch * per_q * k * sizeof(u64)))) return rc;
+            if ((rc = ci.reserve((size_t)kBatch * per_q * k * sizeof(i64)))) return rc;
             ws_k = k;
         }
         return HIPRAG_OK;
@@ -133,25 +136,41 @@ struct Bm25Index {
             if ((rc = ranges.reserve(plan.size() * sizeof(SlotRange)))) return rc;
             HR_CHECK_HIP(hipMemcpyAsync(ranges.p, plan.data(), plan.size() * sizeof(SlotRange), hipMemcpyHostToDevice, st));
             HR_CHECK_HIP(hipStreamSynchronize(st));  // plan is a stack-local vector; tiny copy
-            HR_CHECK_HIP(hipMemsetAsync(acc.p, 0, (size_t)m * n_docs * sizeof(float), st));
+            HR_CHECK_HIP(hipMemsetAsync(acc.p, 0, (size_t)m * stride() * sizeof(float), st));
             for (int s = 0; s < max_terms; ++s) {
                 if (slot_max[s] == 0) continue;
                 const unsigned gx = (unsigned)((slot_max[s] + kTaatChunk - 1) / kTaatChunk);
                 hipLaunchKernelGGL(taat_kernel, dim3(gx, m), dim3(kTaatThreads), 0, st, doc_ids.as<u32>(), impacts.as<float>(),
-                                   ranges.as<SlotRange>() + (size_t)s * m, acc.as<float>(), n_docs);
+                                   ranges.as<SlotRange>() + (size_t)s * m, acc.as<float>(), stride());
             }
-            hipLaunchKernelGGL(select_f32_kernel<true>, dim3((unsigned)nchunks(), m), dim3(256), 0, st,
-                               (const float*)acc.as<float>(), (i64)n_docs, (i64)n_docs, k, ck.as<u64>(), ci.as<i64>());
-            FinishArgs fa;
-            fa.ck = ck.as<u64>(); fa.ci = ci.as<i64>();
-            fa.out64 = o64p ? o64p + (i64)q0 * k : nullptr;
-            fa.out32 = o32p ? o32p + (i64)q0 * k : nullptr;
-            fa.out_ids = oidp + (i64)q0 * k;
-            fa.ncand = nchunks() * k; fa.id_base = id_base; fa.k = k;
-            const size_t lds = (size_t)kTile * 16 + (size_t)k * 16 + 2 * 4 * sizeof(KeyId);
-            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_finish_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bm25_finish_kernel, dim3(m), dim3(256), lds, st, fa);
+            double* o64q = o64p ? o64p + (i64)q0 * k : nullptr;
+            float* o32q = o32p ? o32p + (i64)q0 * k : nullptr;
+            i64* oidq = oidp + (i64)q0 * k;
+            const i64 wave_cand = nlists() * k;
+            if (k <= 64 && wave_cand <= 16 * 64 * 16) {
+                // fast selectors (topk_device.h): one wave filters 4096 accumulators, then a 16-wave merge per query
+                hipLaunchKernelGGL(select_wave_kernel<true>, dim3((unsigned)(nlists() / 4), m), dim3(256), 0, st,
+                                   (const float*)acc.as<float>(), (i64)stride(), (i64)n_docs, k, ck.as<u64>(), ci.as<i64>());
+                const i64 per_lane = (wave_cand + 1023) / 1024;
+                auto mk = merge_packed_kernel<16>;
+                if (per_lane <= 1) mk = merge_packed_kernel<1>;
+                else if (per_lane <= 2) mk = merge_packed_kernel<2>;
+                else if (per_lane <= 4) mk = merge_packed_kernel<4>;
+                else if (per_lane <= 8) mk = merge_packed_kernel<8>;
+                hipLaunchKernelGGL(mk, dim3(m), dim3(1024), 0, st, (const u64*)ck.as<u64>(), (const i64*)ci.as<i64>(), wave_cand, k,
+                                   id_base, o64q, o32q, oidq);
+            } else {
+                hipLaunchKernelGGL(select_f32_kernel<true>, dim3((unsigned)nchunks(), m), dim3(256), 0, st,
+                                   (const float*)acc.as<float>(), (i64)stride(), (i64)n_docs, k, ck.as<u64>(), ci.as<i64>());
+                FinishArgs fa;
+                fa.ck = ck.as<u64>(); fa.ci = ci.as<i64>();
+                fa.out64 = o64q; fa.out32 = o32q; fa.out_ids = oidq;
+                fa.ncand = nchunks() * k; fa.id_base = id_base; fa.k = k;
+                const size_t lds = (size_t)kTile * 16 + (size_t)k * 16 + 2 * 4 * sizeof(KeyId);
+                HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_finish_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(bm25_finish_kernel, dim3(m), dim3(256), lds, st, fa);
+            }
             HR_CHECK_HIP(hipGetLastError());
             queries += m;
             bytes_alg += (i64)m * n_docs * 8;

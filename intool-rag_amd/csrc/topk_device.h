@@ -361,4 +361,51 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const float* __restric
     }
 }
 
+// Final merge of select_wave_kernel's per-wave lists for value/index problems (BM25): one 16-wave workgroup per query
+// reduces ncand = nlists*K1 (key, id) candidates to the top-k; NPL = candidates per lane in the first level.
+// Writes score (fp32, also as fp64 if out64) and id + id_base; exhausted ranks: -FLT_MAX / -1.
+template <int NPL>
+__global__ __launch_bounds__(1024) void merge_packed_kernel(const u64* __restrict__ ck, const i64* __restrict__ ci, i64 ncand,
+                                                           int k, i64 id_base, double* __restrict__ out64,
+                                                           float* __restrict__ out32, i64* __restrict__ out_ids)
+{
+    __shared__ u64 lists[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;
+    const u64* sk = ck + (i64)q * ncand;
+    const i64* si = ci + (i64)q * ncand;
+    {
+        u64 c[NPL];
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const i64 i = ((i64)wave * NPL + n) * 64 + lane;
+            c[n] = 0;
+            if (i < ncand) {
+                const u64 kk = sk[i];
+                if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
+            }
+        }
+        WaveListPacked L;
+        wave_topk_packed<NPL>(c, k, L);
+        lists[wave * 64 + lane] = lane < k ? L.e : 0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        u64 c[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) c[n] = lists[n * 64 + lane];
+        WaveListPacked L;
+        wave_topk_packed<16>(c, k, L);
+        if (lane < k) {
+            const i64 o = (i64)q * k + lane;
+            const bool ok = L.e != 0;
+            const float s = ok ? packed_value(L.e) : -3.402823466e+38f;
+            if (out64) out64[o] = ok ? (double)s : -1.7976931348623157e+308;
+            if (out32) out32[o] = s;
+            out_ids[o] = ok ? (i64)packed_index(L.e) + id_base : -1;
+        }
+    }
+}
+
 }  // namespace hiprag

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""
+Hybrid retrieval benchmark = BASELINE config 2: 1M chunks, dense flat-IP top-50 + BM25 term-at-a-time top-50 + RRF
+fuse -> top-10 on one MI355X, ranks checked bit-exact against the CPU oracle on a sample of the queries.
+
+Synthetic data (SURVEY.md 8d shapes): unit Gaussian vectors; V = 262,144 terms, doc length 64 + (i*2654435761 mod 256),
+term ids ~ Zipf(s=1) by inverse CDF (drawn on the GPU with torch's generator, seed 777), tf = multiplicity; 6 distinct
+query terms from ranks >= 16.  Prints one JSON line: queries/s for the three legs and fused, BM25 algorithmic bytes/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "intool-rag_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--terms", type=int, default=262144)
+    ap.add_argument("--nq", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--check", type=int, default=8, help="queries verified against the CPU oracle")
+    args = ap.parse_args()
+    import torch
+    from hiprag import HipBM25, HipFlatIndex, build_postings, rrf_fuse_device
+    from oracle import hybrid_oracle as ho
+    dev = torch.device("cuda", 0)
+    N, V = args.docs, args.terms
+
+    # ---- dense index --------------------------------------------------------------------------------
+    index = HipFlatIndex(args.dim, "ip")
+    host_rows = []
+    for c in range(0, N, 125000):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + c // 125000)
+        x = torch.randn((min(125000, N - c), args.dim), generator=g, device=dev)
+        x /= x.norm(dim=1, keepdim=True)
+        index.add_device(x)
+        if c < 125000 * 1 and args.check:
+            pass
+        host_rows.append(x[:0].cpu().numpy())   # rows are re-generated for the oracle check below (saves host RAM)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    queries = torch.randn((args.nq, args.dim), generator=gq, device=dev)
+    queries /= queries.norm(dim=1, keepdim=True)
+
+    # ---- postings -----------------------------------------------------------------------------------
+    t0 = time.time()
+    i = torch.arange(N, dtype=torch.int64, device=dev)
+    doc_len = 64 + (i * 2654435761) % 256
+    cdf = torch.cumsum(1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=dev), 0)
+    cdf /= cdf[-1].clone()
+    gt = torch.Generator(device=dev)
+    gt.manual_seed(777)
+    total = int(doc_len.sum().item())
+    u = torch.rand(total, generator=gt, device=dev, dtype=torch.float64)
+    term = torch.clamp(torch.searchsorted(cdf, u), max=V - 1)
+    doc = torch.repeat_interleave(i, doc_len)
+    postings = build_postings(doc.cpu().numpy(), term.cpu().numpy(), N, V, doc_len.cpu().numpy())
+    del u, term, doc
+    build_s = time.time() - t0
+    bm25 = HipBM25(postings)
+    sparse_q = ho.synthetic_sparse_queries(args.nq, n_terms=V, terms_per_query=6, seed=888, min_rank=16)
+
+    depth, k = args.depth, args.k
+
+    def run_dense():
+        return index.search_device(queries, depth)
+
+    def run_sparse():
+        return bm25.search_device(sparse_q, depth)
+
+    def timeit(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps, out
+
+    t_dense, (d64, d32, dids) = timeit(run_dense)
+    b0 = bm25.stats()
+    t_sparse, (s64, s32, sids) = timeit(run_sparse, reps=1)
+    b1 = bm25.stats()
+    t_fuse, (fs, fids) = timeit(lambda: rrf_fuse_device(dids, sids, k))
+
+    def hybrid():
+        a = index.search_device(queries, depth)
+        b = bm25.search_device(sparse_q, depth)
+        return rrf_fuse_device(a[2], b[2], k)
+
+    t_all, (hs, hids) = timeit(hybrid, reps=2)
+
+    # ---- oracle check on a sample -------------------------------------------------------------------
+    ok = None
+    if args.check:
+        nc = args.check
+        op = ho.Postings(postings.n_docs, postings.n_terms, postings.offsets, postings.doc_ids, postings.impacts)
+        es, ei = ho.bm25_search(op, sparse_q[:nc], depth)
+        ok_sparse = bool(np.array_equal(sids[:nc].cpu().numpy(), ei) and np.array_equal(s32[:nc].cpu().numpy(), es))
+        xs = []
+        for c in range(0, N, 125000):
+            g = torch.Generator(device=dev)
+            g.manual_seed(1234 + c // 125000)
+            x = torch.randn((min(125000, N - c), args.dim), generator=g, device=dev)
+            x /= x.norm(dim=1, keepdim=True)
+            xs.append(x.cpu().numpy())
+        xh = np.concatenate(xs)
+        ds, di = ho.flat_search(xh, queries[:nc].cpu().numpy(), depth, ho.METRIC_IP)
+        ok_dense = bool(np.array_equal(dids[:nc].cpu().numpy(), di))
+        efs, efi = ho.rrf_fuse(di, ei, k)
+        ok_fused = bool(np.array_equal(hids[:nc].cpu().numpy(), efi) and np.array_equal(hs[:nc].cpu().numpy(), efs))
+        ok = {"dense_ids": ok_dense, "bm25_ids_scores": ok_sparse, "fused_ids_scores": ok_fused, "queries_checked": nc}
+    bytes_sparse = (b1["bytes_algorithmic"] - b0["bytes_algorithmic"])
+    print(json.dumps({
+        "workload": f"configs[2]: {N} chunks, dense IP top-{depth} + BM25 TAAT top-{depth} + RRF -> top-{k}",
+        "nq": args.nq, "postings": int(postings.offsets[-1]), "postings_build_s": round(build_s, 1),
+        "dense_qps": round(args.nq / t_dense, 1), "bm25_qps": round(args.nq / t_sparse, 1),
+        "rrf_qps": round(args.nq / t_fuse, 1), "hybrid_qps": round(args.nq / t_all, 1),
+        "bm25_algorithmic_GBs": round(bytes_sparse / t_sparse / 1e9, 1),
+        "bm25_postings_per_query": int((b1["postings_touched"] - b0["postings_touched"]) / args.nq),
+        "oracle_check": ok}))
+
+
+if __name__ == "__main__":
+    main()
