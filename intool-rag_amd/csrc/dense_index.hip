@@ -211,15 +211,18 @@ __device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (
                  fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
 }
 
-// Park one block's lane maximum; on the last block of a chunk (or of the wave's range) write the chunk out.
-// sw = this wave's LDS scratch [kChunk][64]; j = index of blk inside its chunk; only this wave touches sw (LDS ops of a
-// wave execute in order, so no barrier).  Plain stores: with the ring loads hidden in asm they are the only VMEM ops
-// hipcc sees here, so they never make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
-__device__ __forceinline__ void park_and_flush(float* sw, float m, int64_t blk, int64_t b0, int64_t b1, int lane,
+// Park one block's lane maximum in a 16-register shift chain (mh[0] = newest); on the last block of a chunk (or of the
+// wave's range) write the chunk out as one run per lane.  Registers, not LDS: the query tile already takes 128 KiB and
+// the remaining 32 KiB must stay free so that the tail kernels of earlier passes can be co-resident with a scan
+// workgroup.  Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
+// make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
+__device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int64_t blk, int64_t b0, int64_t b1, int lane,
                                                const ScanArgs& a)
 {
+#pragma unroll
+    for (int t = kChunk - 1; t > 0; --t) mh[t] = mh[t - 1];
+    mh[0] = m;
     const int j = (int)((blk - b0) % kChunk);
-    sw[j * 64 + lane] = m;
     if (j != kChunk - 1 && blk != b1 - 1) return;
     const int cnt = j + 1;
     const int64_t cb = blk - j;
@@ -227,11 +230,12 @@ __device__ __forceinline__ void park_and_flush(float* sw, float m, int64_t blk, 
     float* dst = a.gmax + (int64_t)qb * a.gstride + 2 * cb + (int64_t)h * cnt;
     if (cnt == kChunk) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-            reinterpret_cast<float4*>(dst)[v] = make_float4(sw[(4 * v + 0) * 64 + lane], sw[(4 * v + 1) * 64 + lane],
-                                                            sw[(4 * v + 2) * 64 + lane], sw[(4 * v + 3) * 64 + lane]);
+        for (int v = 0; v < 4; ++v)   // block cb + t sits in mh[15 - t]
+            reinterpret_cast<float4*>(dst)[v] = make_float4(mh[15 - 4 * v], mh[14 - 4 * v], mh[13 - 4 * v], mh[12 - 4 * v]);
     } else {
-        for (int t = 0; t < cnt; ++t) dst[t] = sw[t * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (t < cnt) dst[cnt - 1 - t] = mh[t];
     }
 }
 
@@ -254,7 +258,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);  // pieces in this wave's stream
     const float4* base = a.xb + b0 * P * kPieceVec4;  // wave-uniform; lanes add 16 B each through the VGPR offset
-    float* sw = reinterpret_cast<float*>(qs + P * kPieceVec4) + wave * (kChunk * 64);  // lane-maxima scratch
+    float mh[kChunk];  // lane maxima of the current chunk (shift chain)
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) mh[t] = 0.f;
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
         }
         if (METRIC == HIPRAG_METRIC_L2)  // the 4 norm loads were issued before this block's P >= RING ring re-arms
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-        park_and_flush(sw, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
+        park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's clamped re-arms are still in flight
 }
@@ -383,6 +389,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = a.P;
     const int npairs = P / 2;
+    // The scan is statically partitioned, so a CU that also hosts a tail workgroup of an earlier pass becomes the
+    // straggler of the whole launch: let the scan's waves win issue arbitration against co-resident tail waves.
+    __builtin_amdgcn_s_setprio(3);
 
     const int64_t gw = (int64_t)blockIdx.x * NWAVES + wave;
     const int64_t W = (int64_t)gridDim.x * NWAVES;
@@ -391,7 +400,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);
     const float4* base = a.xb + b0 * P * kPieceVec4;
-    float* sw = reinterpret_cast<float*>(qs + P * kPieceVec4) + wave * (kChunk * 64);  // lane-maxima scratch
+    float mh[kChunk];  // lane maxima of the current chunk (shift chain)
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) mh[t] = 0.f;
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             for (int i = 0; i < 16; ++i) t += acc[i];
             if (t == 123.456f) a.gmax[0] = t;
         } else {
-            park_and_flush(sw, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
+            park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -699,12 +710,12 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
 constexpr int kFinWaves = 16;
 constexpr int kCandPerQuery = 1024;  // 64 group slots x 16 rows
 
-template <int NPL>
-__global__ __launch_bounds__(kFinWaves * 64) void fin_merge_kernel(FinishArgs a)
+template <int NPL, int NW>
+__global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
 {
-    __shared__ u64 lists[kFinWaves * 64];
-    __shared__ double dred[kFinWaves];
-    constexpr int NT = kFinWaves * 64;
+    __shared__ u64 lists[NW > 1 ? NW * 64 : 1];
+    __shared__ double dred[NW];
+    constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;
@@ -717,35 +728,38 @@ __global__ __launch_bounds__(kFinWaves * 64) void fin_merge_kernel(FinishArgs a)
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
-    if (lane == 0) dred[wave] = qpart;
-    {
-        const u64* sk = a.ck + (int64_t)q * a.ncand;
-        const i64* si = a.ci + (int64_t)q * a.ncand;
-        u64 c[NPL];
+    const u64* sk = a.ck + (int64_t)q * a.ncand;
+    const i64* si = a.ci + (int64_t)q * a.ncand;
+    u64 c[NPL];
 #pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int64_t i = ((int64_t)wave * NPL + n) * 64 + lane;
-            c[n] = 0;
-            if (i < a.ncand) {
-                const u64 kk = sk[i];
-                if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
-            }
+    for (int n = 0; n < NPL; ++n) {
+        const int64_t i = ((int64_t)wave * NPL + n) * 64 + lane;
+        c[n] = 0;
+        if (i < a.ncand) {
+            const u64 kk = sk[i];
+            if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
         }
-        WaveListPacked L;
-        wave_topk_packed<NPL>(c, K1, L);
-        lists[wave * 64 + lane] = lane < K1 ? L.e : 0;
     }
+    WaveListPacked L;
+    wave_topk_packed<NPL>(c, K1, L);
+    if (NW == 1) {  // the usual case (<= 512 candidates): one wave, no LDS, runs beside a resident scan workgroup
+        a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L.e : 0;
+        if (lane == 0) a.qn2[q] = qpart;
+        return;
+    }
+    if (lane == 0) dred[wave] = qpart;
+    lists[wave * 64 + lane] = lane < K1 ? L.e : 0;
     __syncthreads();
     if (wave == 0) {
-        u64 c[kFinWaves];
+        u64 c2[NW];
 #pragma unroll
-        for (int n = 0; n < kFinWaves; ++n) c[n] = lists[n * 64 + lane];
-        WaveListPacked L;
-        wave_topk_packed<kFinWaves>(c, K1, L);
-        a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L.e : 0;
+        for (int n = 0; n < NW; ++n) c2[n] = lists[n * 64 + lane];
+        WaveListPacked L2;
+        wave_topk_packed<NW>(c2, K1, L2);
+        a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L2.e : 0;
         if (lane == 0) {
             double qn2 = 0.0;
-            for (int w = 0; w < kFinWaves; ++w) qn2 += dred[w];
+            for (int w = 0; w < NW; ++w) qn2 += dred[w];
             a.qn2[q] = qn2;
         }
     }
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(kFinWaves * 64) void fin_merge_kernel(FinishArgs a)
 template <int METRIC>
 __global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
 {
-    extern __shared__ float qv[];  // d_pad floats
+    extern __shared__ float qv[];  // d_pad floats (4 KiB: fits beside a resident scan workgroup)
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const int j = blockIdx.x, q = blockIdx.y;
     const int dpad = a.P * 8;
@@ -1100,7 +1114,7 @@ struct DenseIndex {
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = split_mode;
         w.split = split ? 1 : 0;
-        const size_t scan_lds = (size_t)P * 1024 + 8 * kChunk * 64 * sizeof(float);  // query tile + lane-maxima scratch
+        const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
@@ -1160,13 +1174,12 @@ struct DenseIndex {
             fa.cand_k = fin_base + (size_t)kMaxQ * 64;
             fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)kMaxQ * kCandPerQuery);
             fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)kMaxQ * kCandPerQuery);
-            const int64_t per_lane = (wave_cand + kFinWaves * 64 - 1) / (kFinWaves * 64);
-            void (*mrg)(FinishArgs) = fin_merge_kernel<16>;
-            if (per_lane <= 1) mrg = fin_merge_kernel<1>;
-            else if (per_lane <= 2) mrg = fin_merge_kernel<2>;
-            else if (per_lane <= 4) mrg = fin_merge_kernel<4>;
-            else if (per_lane <= 8) mrg = fin_merge_kernel<8>;
-            hipLaunchKernelGGL(mrg, dim3(nq), dim3(kFinWaves * 64), 0, st, fa);
+            if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
+            else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
+            else if (wave_cand <= 256) hipLaunchKernelGGL((fin_merge_kernel<4, 1>), dim3(nq), dim3(64), 0, st, fa);
+            else if (wave_cand <= 512) hipLaunchKernelGGL((fin_merge_kernel<8, 1>), dim3(nq), dim3(64), 0, st, fa);
+            else if (wave_cand <= 2048) hipLaunchKernelGGL((fin_merge_kernel<8, 4>), dim3(nq), dim3(256), 0, st, fa);
+            else hipLaunchKernelGGL((fin_merge_kernel<16, 16>), dim3(nq), dim3(1024), 0, st, fa);
             hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3(Kp, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
             hipLaunchKernelGGL(fin_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, fa);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
@@ -1261,8 +1274,9 @@ int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_h
     HR_REQUIRE(d > 0, "d must be positive (got %d)", d);
     HR_REQUIRE(metric == HIPRAG_METRIC_IP || metric == HIPRAG_METRIC_L2, "unknown metric %d", metric);
     const int P = ((d + 127) / 128) * 16;
-    if ((size_t)P * 1024 + 8 * 16 * 64 * 4 > 160 * 1024) {
-        set_error("d=%d needs %d KiB of LDS for the query tile (+32 KiB scratch); the scan supports d <= 1024", d, P);
+    if ((size_t)P * 1024 > 128 * 1024) {
+        set_error("d=%d needs %d KiB of LDS for the query tile; the scan supports d <= 1024 (128 KiB, leaving 32 KiB per CU "
+                  "for the tail kernels of earlier passes)", d, P);
         return HIPRAG_E_UNSUPPORTED;
     }
     auto ix = std::make_shared<DenseIndex>();
