@@ -9,7 +9,7 @@ resident in HBM: scan (fp32 MFMA, HBM-bound) -> group select -> fp64 re-score + 
 all-gather of the packed partial top-k + canonical merge).
 
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): the 1M rows are sharded row-wise
-across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to three steps are
+across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to six steps are
 in flight so the latency-bound tail of a step (selection, fp64 re-score, exchange, merge) runs beside later scans.
 
 Prints ONE JSON line on rank 0.  Extra objects:
@@ -105,7 +105,7 @@ def main():
     queries /= queries.norm(dim=1, keepdim=True)
     nb = N_QUERIES // BATCH
 
-    IN_FLIGHT = 3      # steps in flight (the library has 4 workspace slots); results are consumed in order
+    IN_FLIGHT = 6      # steps in flight (the library has 8 workspace slots); results are consumed in order
 
     def run_steps(n, first):
         """n pipelined steps: while step i scans, the tails (select / re-score / all-gather / merge) of the previous

@@ -76,7 +76,7 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 /* Two-phase form of one pass (nq <= 32) for callers that pipeline: begin = query fragments + index scan into
- * workspace `slot` (0..3); finish = group selection, fp64 re-score, top-k, certificate / fallback out of that slot.
+ * workspace `slot` (0..7); finish = group selection, fp64 re-score, top-k, certificate / fallback out of that slot.
  * begin(slot s) of a later pass must be ordered after finish(slot s) of the pass that used it (stream order or an event); the two phases
  * of one pass may run on different streams if finish waits for begin.  search_dev == begin + finish on slot 0. */
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);

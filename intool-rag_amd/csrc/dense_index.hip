@@ -971,7 +971,7 @@ struct DenseIndex {
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
     struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0; };
-    static constexpr int kSlots = 4;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
+    static constexpr int kSlots = 8;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
     int ws_k = 0;
@@ -1371,7 +1371,7 @@ int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int3
     GET_INDEX(h);
     HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_begin takes 1..%d queries (got %d)", kMaxQ, nq);
     HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
-    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..3");
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     HR_REQUIRE(q_dev, "null device pointer");
     int32_t rc = ix->prepare(k);
     if (rc) return rc;
@@ -1384,7 +1384,7 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
     GET_INDEX(h);
     HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_finish takes 1..%d queries (got %d)", kMaxQ, nq);
     HR_REQUIRE(k > 0 && k <= ix->ws_k, "k=%d was not prepared by search_begin", k);
-    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..3");
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
     return ix->finish_dev(q_dev, nq, k, slot, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
 }
@@ -1528,6 +1528,14 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             if (hipEventElapsedTime(&ms, ix->evs[2 * i], ix->evs[2 * i + 1]) == hipSuccess) { sum += ms; ++ok; }
         }
         if (ok) { out->avg_scan_ms = (float)(sum / ok); out->timed_passes = ok; }
+        if (getenv("HIPRAG_DEBUG_GAPS") && ix->ev_count <= DenseIndex::kEvRing) {
+            double gsum = 0.0; int64_t gn = 0;
+            for (int64_t i = 0; i + 1 < n; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ix->evs[2 * i + 1], ix->evs[2 * i + 2]) == hipSuccess) { gsum += ms; ++gn; }
+            }
+            if (gn) fprintf(stderr, "[hiprag] mean gap between scan launches: %.2f us over %lld gaps\n", gsum / gn * 1e3, (long long)gn);
+        }
     }
     return HIPRAG_OK;
 }

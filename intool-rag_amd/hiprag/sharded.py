@@ -19,7 +19,7 @@ from typing import List, Tuple
 from .index import HipFlatIndex, merge_topk_device
 
 MAX_PASS = 32   # queries per scan pass (the N dimension of the MFMA tile)
-N_SLOTS = 4     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
+N_SLOTS = 8     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
 
 
 def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
@@ -107,15 +107,18 @@ class ShardedFlatIndex:
                 work = all_gather_packed(pack, c["gathered"], self.group, async_op=True)
         return (work, slot, k)
 
-    def search_end(self, ticket):
-        """-> (scores64, scores32, ids) [nq,k]; the caller's current stream is made to wait for them."""
+    def search_end(self, ticket, wait: bool = True):
+        """-> (scores64, scores32, ids) [nq,k].  With wait=True (default) the caller's current stream is made to wait
+        for them; wait=False only finishes enqueueing (merge after the exchange) and leaves ordering to the caller --
+        `result_event(ticket)` gives the event to wait on, a device synchronise covers everything."""
         import torch
         work, slot, k = ticket
         c = self._bufs[slot]
         main = torch.cuda.current_stream()
-        self._slot_ended[slot] = True
+        self._slot_ended[slot] = wait
         if work is None:
-            main.wait_event(c["done"])
+            if wait:
+                main.wait_event(c["done"])
             return (c["pack"][0].view(torch.float64), c["s32"], c["pack"][1])
         side = self.side[slot]
         with torch.cuda.stream(side):
@@ -123,8 +126,14 @@ class ShardedFlatIndex:
             g = c["gathered"]
             out = merge_topk_device(g[:, 0].view(torch.float64), g[:, 1], k, self.local.metric, out=c["merged"])
             c["fin"].record(side)
-        main.wait_event(c["fin"])
+        if wait:
+            main.wait_event(c["fin"])
         return out
+
+    def result_event(self, ticket):
+        """Event that completes when the results of `ticket` are final (after search_end)."""
+        work, slot, _ = ticket
+        return self._bufs[slot]["fin" if work is not None else "done"]
 
     def search_device(self, q, k: int):
         """Any number of queries; passes of 32 are pipelined internally."""
