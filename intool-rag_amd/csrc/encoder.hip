@@ -57,14 +57,31 @@ struct GemmArgs {
     float* out_f32;     // [M, N]
 };
 
+// LDS tile image: 128 rows x 64 bf16 = 128-B rows of eight 16-B chunks, chunk kc of row r stored at slot kc ^ (r & 7).
+// One global_load_lds_dwordx4 wave-instruction fills eight whole rows (lane = row*8 + slot fetches chunk slot ^ (row&7)
+// of its row: LDS side lane-linear as the DMA requires, global side 128 B contiguous per row), and the MFMA fragment
+// reads (16 rows x one chunk per ds_read_b128 lane group) hit 16 distinct 16-B bank slots: conflict-free both ways.
+__device__ __forceinline__ int tile_unit(int row, int kc) { return row * 8 + (kc ^ (row & 7)); }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int EPI>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
 {
-    __shared__ bf16x8 lds[2][2][BM * BK / 8];  // [buffer][A|B][unit]; 2 x 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ bf16x8 lds[2][2][BM * BK / 8];  // [buffer][A|B][unit]; 64 KiB, reused as the fp32 C tile in the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;    // 2 x 2 waves, 64 x 64 each
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int r16 = lane & 15, kq = lane >> 4;
+
+    // XCD-aware block mapping: consecutive block ids go round-robin over the 8 XCDs, so give each XCD a contiguous range
+    // of tiles; inside it the N index runs fastest, i.e. the blocks sharing an A row-panel share one L2.
+    const int nbn = g.N / BN;
+    const int nblk = gridDim.x;
+    const int per = nblk >> 3, rem = nblk & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+    const int m0 = (pid / nbn) * BM, n0 = (pid % nbn) * BN;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -72,80 +89,107 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread: chunk c -> row c/8, k-chunk c%8
-    bf16x8 ra[4], rb[4];
-    auto load_tiles = [&](int k0) {
+    // staging by LDS-DMA: 16 wave-instructions of 1 KiB per operand tile, 4 per wave
+    const int srow = lane >> 3, sslot = lane & 7;
+    auto stage = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = tid + kGemmThreads * i;
-            const int row = c >> 3, kc = c & 7;
-            ra[i] = *reinterpret_cast<const bf16x8*>(g.A + (size_t)(m0 + row) * g.K + k0 + kc * 8);
-            rb[i] = *reinterpret_cast<const bf16x8*>(g.W + (size_t)(n0 + row) * g.K + k0 + kc * 8);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + kGemmThreads * i;
-            const int row = c >> 3, kc = c & 7;
-            lds[buf][0][swz_unit(kc, row, BM)] = ra[i];
-            lds[buf][1][swz_unit(kc, row, BN)] = rb[i];
+            const int inst = wave * 4 + i;
+            const int row = inst * 8 + srow;
+            const int kc = sslot ^ (row & 7);
+            const bf16* ga = g.A + (size_t)(m0 + row) * g.K + k0 + kc * 8;
+            const bf16* gb = g.W + (size_t)(n0 + row) * g.K + k0 + kc * 8;
+            __builtin_amdgcn_global_load_lds((const void*)ga, (lds_ptr_t)&lds[buf][0][inst * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)gb, (lds_ptr_t)&lds[buf][1][inst * 64], 16, 0, 0);
         }
     };
 
     const int nk = g.K / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);  // global loads fly under this tile's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+        __syncthreads();                                   // ... everyone's has, and buffer buf^1 is no longer being read
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);    // DMA of the next tile flies under this tile's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
             const int kc = ks * 4 + kq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = lds[buf][0][swz_unit(kc, wr * 64 + i * 16 + r16, BM)];
+            for (int i = 0; i < 4; ++i) af[i] = lds[buf][0][tile_unit(wr * 64 + i * 16 + r16, kc)];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = lds[buf][1][swz_unit(kc, wc * 64 + j * 16 + r16, BN)];
+            for (int j = 0; j < 4; ++j) bfr[j] = lds[buf][1][tile_unit(wc * 64 + j * 16 + r16, kc)];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
     }
+    __syncthreads();  // all fragment reads done: the staging buffers become the C tile
 
-    // epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + 4*kq + r][n0 + wc*64 + j*16 + r16]
+    // ---- epilogue: C tile through LDS so that every global store is a 16-byte vector ---------------------------------
+    float* ct = reinterpret_cast<float*>(&lds[0][0][0]);  // [128][128] fp32 = 64 KiB
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + r16;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wr * 64 + i * 16 + 4 * kq + r) * BN + wc * 64 + j * 16 + r16] = acc[i][j][r];
+    __syncthreads();
+
+    if (EPI == EPI_QKV && n0 >= 2 * g.H) {
+        // V third: stored transposed [seq, head, d, S]: thread = one column (d) x 8 consecutive tokens -> one 16-B store
+        const int col = tid & 127, half = tid >> 7;
+        const int n = n0 + col;
         const float bias = g.bias[n];
+        const int hn = n - 2 * g.H;
+        const int head = hn >> 6, dd = hn & 63;
+        for (int rc = half; rc < 16; rc += 2) {
+            const int m = m0 + rc * 8;
+            if (m >= g.M) break;
+            const int seq = m / g.S, s0 = m - seq * g.S;
+            bf16x8 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int t = 0; t < 8; ++t) v[t] = (bf16)(ct[(rc * 8 + t) * BN + col] + bias);
+            *reinterpret_cast<bf16x8*>(g.vt + (((size_t)seq * g.heads + head) * 64 + dd) * g.S + s0) = v;
+        }
+        return;
+    }
+    // row-major outputs: thread = 8 consecutive columns of one row; 16 column groups x 128 rows = 2048 vectors
+    for (int v = tid; v < BM * (BN / 8); v += kGemmThreads) {
+        const int row = v >> 4, cg = v & 15;
+        const int m = m0 + row, n = n0 + cg * 8;
+        if (m >= g.M) continue;
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * BN + cg * 8);
+        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * BN + cg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+        float x[8] = {c0.x + b0.x, c0.y + b0.y, c0.z + b0.z, c0.w + b0.w, c1.x + b1.x, c1.y + b1.y, c1.z + b1.z, c1.w + b1.w};
+        if (EPI == EPI_QKV) {
+            const int which = n / g.H, hn = n - which * g.H;   // which in {0 (q), 1 (k)}: the V third returned above
+            const int head = hn >> 6, dd = hn & 63;
+            const int seq = m / g.S, s = m - seq * g.S;
+            const float scale = which == 0 ? 0.125f : 1.f;     // 1/sqrt(64) folded into q, exact
+            bf16x8 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + 4 * kq + r;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (EPI == EPI_QKV) {
-                    const int which = n / g.H, hn = n - which * g.H;
-                    const int head = hn >> 6, dd = hn & 63;
-                    const int seq = m / g.S, s = m - seq * g.S;
-                    const size_t hb = ((size_t)seq * g.heads + head);
-                    if (which == 0) g.q[(hb * g.S + s) * 64 + dd] = (bf16)(v * 0.125f);  // 1/sqrt(64), exact
-                    else if (which == 1) g.k[(hb * g.S + s) * 64 + dd] = (bf16)v;
-                    else g.vt[(hb * 64 + dd) * g.S + s] = (bf16)v;
-                } else if (EPI == EPI_GELU) {
-                    v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                    g.out_bf16[(size_t)m * g.N + n] = (bf16)v;
-                } else {
-                    v += (float)g.resid[(size_t)m * g.N + n];
-                    g.out_f32[(size_t)m * g.N + n] = v;
-                }
-            }
+            for (int t = 0; t < 8; ++t) o[t] = (bf16)(x[t] * scale);
+            bf16* dst = (which == 0 ? g.q : g.k) + ((((size_t)seq * g.heads + head) * g.S + s) * 64 + dd);
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else if (EPI == EPI_GELU) {
+            bf16x8 o;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = (bf16)(0.5f * x[t] * (1.f + erff(x[t] * 0.70710678118654752f)));
+            *reinterpret_cast<bf16x8*>(g.out_bf16 + (size_t)m * g.N + n) = o;
+        } else {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (size_t)m * g.N + n);
+            float4 o0, o1;
+            o0.x = x[0] + (float)rs[0]; o0.y = x[1] + (float)rs[1]; o0.z = x[2] + (float)rs[2]; o0.w = x[3] + (float)rs[3];
+            o1.x = x[4] + (float)rs[4]; o1.y = x[5] + (float)rs[5]; o1.z = x[6] + (float)rs[6]; o1.w = x[7] + (float)rs[7];
+            float* dst = g.out_f32 + (size_t)m * g.N + n;
+            *reinterpret_cast<float4*>(dst) = o0;
+            *reinterpret_cast<float4*>(dst + 4) = o1;
         }
     }
 }
@@ -425,24 +469,24 @@ struct Encoder {
             g.q = q.as<bf16>(); g.k = k.as<bf16>(); g.vt = vt.as<bf16>(); g.S = S; g.heads = heads; g.H = H;
             // rows >= T exist only as GEMM padding; the QKV scatter must not write them
             g.M = T;
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3(3 * H / BN, M / BM), dim3(kGemmThreads), 0, st, g);
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
             hipLaunchKernelGGL(attention_kernel, dim3(S / 64, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
                                (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
                                heads, H);
             GemmArgs o{};
             o.A = ctx.as<bf16>(); o.W = (const bf16*)L.wo; o.bias = (const float*)L.bo; o.M = M; o.N = H; o.K = H;
             o.resid = X; o.out_f32 = pre.as<float>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3(H / BN, M / BM), dim3(kGemmThreads), 0, st, o);
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, o);
             hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps);
             GemmArgs f1{};
             f1.A = X; f1.W = (const bf16*)L.w1; f1.bias = (const float*)L.b1; f1.M = M; f1.N = F; f1.K = H;
             f1.out_bf16 = ffn.as<bf16>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3(F / BN, M / BM), dim3(kGemmThreads), 0, st, f1);
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3((F / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f1);
             GemmArgs f2{};
             f2.A = ffn.as<bf16>(); f2.W = (const bf16*)L.w2; f2.bias = (const float*)L.b2; f2.M = M; f2.N = H; f2.K = F;
             f2.resid = X; f2.out_f32 = pre.as<float>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3(H / BN, M / BM), dim3(kGemmThreads), 0, st, f2);
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f2);
             hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps);
         }
