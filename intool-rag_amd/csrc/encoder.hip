@@ -57,6 +57,17 @@ struct GemmArgs {
     float* out_f32;     // [M, N]
 };
 
+// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): far below the bf16 resolution of the value it feeds, and a third of
+// the instructions of the library erff in the FFN epilogue (the H->F GEMM is the largest single kernel of the encoder).
+__device__ __forceinline__ float erf_as(float x)
+{
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float y = 1.f - poly * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+
 // LDS tile image: 128 rows x 64 bf16 = 128-B rows of eight 16-B chunks, chunk kc of row r stored at slot kc ^ (r & 7).
 // One global_load_lds_dwordx4 wave-instruction fills eight whole rows (lane = row*8 + slot fetches chunk slot ^ (row&7)
 // of its row: LDS side lane-linear as the DMA requires, global side 128 B contiguous per row), and the MFMA fragment
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
         } else if (EPI == EPI_GELU) {
             bf16x8 o;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = (bf16)(0.5f * x[t] * (1.f + erff(x[t] * 0.70710678118654752f)));
+            for (int t = 0; t < 8; ++t) o[t] = (bf16)(0.5f * x[t] * (1.f + erf_as(x[t] * 0.70710678118654752f)));
             *reinterpret_cast<bf16x8*>(g.out_bf16 + (size_t)m * g.N + n) = o;
         } else {
             const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (size_t)m * g.N + n);
@@ -208,18 +219,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                        const float* __restrict__ beta, bf16* __restrict__ y, int M, int H,
                                                        float eps)
 {
+    // one wave per row; the row is read ONCE (16 B per lane per load, kept in registers: H <= 2048 -> <= 8 float4)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (size_t)row * H;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * H);
+    const int nv = H >> 8;  // float4 per lane (H is a multiple of 128; a 128-wide remainder is handled by half the lanes)
+    float4 v[8];
     float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += xr[c];
+    const int nvec = H >> 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    (void)nv;
     const float mean = wave_sum(s) / (float)H;
-    float v = 0.f;
-    for (int c = lane; c < H; c += 64) { const float t = xr[c] - mean; v += t * t; }
-    const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
-    bf16* yr = y + (size_t)row * H;
-    for (int c = lane; c < H; c += 64) yr[c] = (bf16)((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * H);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            const float4 g = g4[c], b = b4[c];
+            bf16x4 o;
+            o[0] = (bf16)((v[i].x - mean) * rstd * g.x + b.x);
+            o[1] = (bf16)((v[i].y - mean) * rstd * g.y + b.y);
+            o[2] = (bf16)((v[i].z - mean) * rstd * g.z + b.z);
+            o[3] = (bf16)((v[i].w - mean) * rstd * g.w + b.w);
+            yr[c] = o;
+        }
+    }
 }
 
 // K5: embeddings.  tokens [nseq, S] (pad beyond len), position id = s + pad_id + 1 for real tokens, pad_id for pads
