@@ -70,3 +70,28 @@ def test_host_bm25_builder_matches_oracle_spec():
     assert np.array_equal(a.impacts, b.impacts)
     sh = a.shard(100, 350)
     assert sh.n_docs == 250 and int(sh.offsets[-1]) == int(((a.doc_ids >= 100) & (a.doc_ids < 350)).sum())
+
+
+def test_service_facade_uses_the_installed_provider():
+    import asyncio
+    import rag.llm.embeddings.factory as f
+    from rag.llm.embeddings import service
+
+    class P:
+        async def embed_single(self, text, instruction=None):
+            return [float(len(text))]
+
+        async def embed_batch(self, texts, instruction=None):
+            return [[float(len(t))] for t in texts]
+
+        def dimension(self):
+            return 1
+
+    f.set_embedding_provider(P())
+    try:
+        assert asyncio.run(service.embed("abc")) == [3.0]
+        assert asyncio.run(service.embed_batch(["a", "bb"])) == [[1.0], [2.0]]
+        assert asyncio.run(service.embed_batch([])) == []
+        assert service.embedding_dim() == 1
+    finally:
+        f.set_embedding_provider(None)
