@@ -47,6 +47,7 @@ except Exception as _e:  # library not built / not on sys.path
     _HIP_IMPORT_ERROR = _e
 
 INDEX_SUFFIX = "_hip.index"
+FAISS_SUFFIX = "_faiss.index"      # files the reference wrote; imported on load (hiprag/faiss_io.py)
 _INDEX_CACHE: Dict[str, "HipFlatIndex"] = {}
 _CHUNK_CACHE: Dict[str, Tuple[float, List[Dict[str, Any]]]] = {}
 _LOCK = threading.Lock()
@@ -73,7 +74,12 @@ class HipIndexReader:
                 self.index = cached
                 return
             try:
-                self.index = HipFlatIndex.load(self.index_path, device=config.HIP_DEVICE)
+                if self.index_path.endswith(FAISS_SUFFIX):
+                    # an index written by the reference's faiss.write_index (faiss_index.py:133): import it as is
+                    from hiprag.faiss_io import load_faiss_flat_into_hip
+                    self.index = load_faiss_flat_into_hip(self.index_path, device=config.HIP_DEVICE)
+                else:
+                    self.index = HipFlatIndex.load(self.index_path, device=config.HIP_DEVICE)
             except Exception as e:
                 raise RuntimeError(f"Failed to load HIP index: {e}")
             _INDEX_CACHE[self.index_path] = self.index
@@ -193,11 +199,15 @@ def open_first_index():
     """(reader, doc_id, chunk list) of the FIRST index file in STORAGE_DIR -- the one the reference searches
     (faiss_index.py:162-176) -- or None when there is no index."""
     storage_path = Path(config.STORAGE_DIR)
+    suffix = INDEX_SUFFIX
     index_files = list(storage_path.glob(f"*{INDEX_SUFFIX}"))
+    if not index_files:                                   # fall back to indices the reference itself wrote
+        suffix = FAISS_SUFFIX
+        index_files = list(storage_path.glob(f"*{FAISS_SUFFIX}"))
     if not index_files:
         return None
     index_path = index_files[0]
-    doc_id = index_path.name[:-len(INDEX_SUFFIX)]
+    doc_id = index_path.name[:-len(suffix)]
     return HipIndexReader(str(index_path)), doc_id, _load_chunk_list(storage_path, doc_id)
 
 
@@ -227,11 +237,13 @@ async def initialize_storage() -> None:
             logger.warning(f"Storage directory not found: {storage_path}")
             return
         count = 0
-        for index_file in storage_path.glob(f"*{INDEX_SUFFIX}"):
+        files = [(f, INDEX_SUFFIX) for f in storage_path.glob(f"*{INDEX_SUFFIX}")]
+        files += [(f, FAISS_SUFFIX) for f in storage_path.glob(f"*{FAISS_SUFFIX}")]
+        for index_file, suffix in files:
             try:
                 HipIndexReader(str(index_file))
                 try:
-                    _load_chunk_list(storage_path, index_file.name[:-len(INDEX_SUFFIX)])
+                    _load_chunk_list(storage_path, index_file.name[:-len(suffix)])
                 except FileNotFoundError:
                     pass
                 count += 1

@@ -229,3 +229,21 @@ def test_hip_embedding_provider_and_reranker_follow_reference_behaviour(gpu, mon
     assert np.allclose(got_logits, ref_logits, atol=5e-2)
     assert [c.chunk_id for c in out] == [chunks[i].chunk_id for i in sorted(range(4), key=lambda i: (-got_logits[i], i))[:2]]
     assert all("rerank_score" in c.metadata for c in out)
+
+
+def test_overlay_reads_index_files_written_by_the_reference_format(gpu, tmp_path, monkeypatch):
+    """A STORAGE_DIR that only holds `{doc}_faiss.index` (the reference's own file) is searchable as is."""
+    import rag.storage.hip_index as hi
+    from hiprag.faiss_io import write_faiss_flat
+    g = GOLD["search_faiss_by_vector"]
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path))
+    hi.clear_caches()
+    x = np.asarray(g["vectors"], dtype=np.float32)
+    write_faiss_flat(str(tmp_path / f"{g['doc_id']}_faiss.index"), x, 1)
+    with open(tmp_path / f"{g['doc_id']}_chunks.json", "w") as f:
+        json.dump(g["chunks_json"], f)
+    asyncio.run(hi.initialize_storage())
+    case = g["cases"][0]
+    got = asyncio.run(hi.search_hip_by_vector(case["query"], limit=case["limit"]))
+    assert [r["chunk_id"] for r in got] == [r["chunk_id"] for r in case["expected"]]
+    hi.clear_caches()
