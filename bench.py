@@ -4,7 +4,7 @@ bench.py -- headline benchmark of the MI355X hybrid-retrieval hot path.
 
 Metric (BASELINE.json): queries/sec (+ p50 retrieve latency) for exact top-10 inner-product search on a
 1M x 1024-d fp32 index.  Workload = BASELINE configs[1]: "1M x 1024-d synthetic vectors, brute-force
-inner-product top-10".  A STEP is one pass of the hot path over one batch of B=32 synthetic queries already
+inner-product top-10".  A STEP is one pass of the hot path over one batch of B=64 synthetic queries already
 resident in HBM: scan (fp32 MFMA, HBM-bound) -> group select -> fp64 re-score + certificate -> (N>1: one RCCL
 all-gather of the packed partial top-k + canonical merge).
 
@@ -34,7 +34,6 @@ sys.path.insert(0, os.path.join(REPO, "intool-rag_amd"))
 N_ROWS = 1_000_000
 DIM = 1024
 TOPK = 10
-BATCH = 32
 N_QUERIES = 4096
 CHUNK = 31250                 # generation unit: N_ROWS/32, so shards of 1,2,4,8,16,32 ranks align to chunks
 HBM_PEAK_GBS = 8000.0
@@ -103,6 +102,7 @@ def main():
     gq.manual_seed(4321)
     queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
     queries /= queries.norm(dim=1, keepdim=True)
+    BATCH = index.pass_queries          # one scan pass per step: 64 queries (32 with HIPRAG_SCAN_MODE=split|f32)
     nb = N_QUERIES // BATCH
 
     IN_FLIGHT = 6      # steps in flight (the library has 8 workspace slots); results are consumed in order
@@ -182,7 +182,7 @@ def main():
         "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
                    "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH,
                    "sharding": f"rows/{world}" if world > 1 else "none",
-                   "exchange": "1 all-gather of [2,32,10] int64 per step" if world > 1 else "none",
+                   "exchange": f"1 all-gather of [2,{BATCH},{TOPK}] int64 per step" if world > 1 else "none",
                    "steps_in_flight": IN_FLIGHT},
         "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),

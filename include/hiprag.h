@@ -75,7 +75,11 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
  * float (may be NULL), out_ids_dev [nq,k] int64. */
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* Two-phase form of one pass (nq <= 32) for callers that pipeline: begin = query fragments + index scan into
+/* Queries one scan pass serves: 64 in the default operand mode (bf16 hi/lo split of the index rows, hi-only query
+ * tiles), 32 with HIPRAG_SCAN_MODE=split (hi/lo on both sides) or =f32 (exact fp32 MFMA).  All modes return the same
+ * exact results; they differ in how wide the certificate's error bound is and how many rows get re-scored. */
+int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n);
+/* Two-phase form of one pass (nq <= hipidx_pass_queries) for callers that pipeline: begin = query fragments + index scan into
  * workspace `slot` (0..7); finish = group selection, fp64 re-score, top-k, certificate / fallback out of that slot.
  * begin(slot s) of a later pass must be ordered after finish(slot s) of the pass that used it (stream order or an event); the two phases
  * of one pass may run on different streams if finish waits for begin.  search_dev == begin + finish on slot 0. */

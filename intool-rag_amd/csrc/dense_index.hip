@@ -40,7 +40,7 @@ namespace {
 constexpr int kRowsPerBlock = 32;
 constexpr int kPieceFloats = 256;
 constexpr int kPieceVec4 = 64;
-constexpr int kMaxQ = 32;          // queries per pass
+constexpr int kMaxQ = 64;          // queries per pass: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
 constexpr int kExRows = 1024;      // rows per workgroup in the exhaustive path (16 KiB of LDS: it must fit BESIDE a
@@ -217,7 +217,7 @@ __device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (
 // workgroup.  Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
 // make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
 __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int64_t blk, int64_t b0, int64_t b1, int lane,
-                                               const ScanArgs& a)
+                                               const ScanArgs& a, int qoff)
 {
 #pragma unroll
     for (int t = kChunk - 1; t > 0; --t) mh[t] = mh[t - 1];
@@ -226,7 +226,7 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
     if (j != kChunk - 1 && blk != b1 - 1) return;
     const int cnt = j + 1;
     const int64_t cb = blk - j;
-    const int h = lane >> 5, qb = lane & 31;
+    const int h = lane >> 5, qb = (lane & 31) + qoff;
     float* dst = a.gmax + (int64_t)qb * a.gstride + 2 * cb + (int64_t)h * cnt;
     if (cnt == kChunk) {
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
         }
         if (METRIC == HIPRAG_METRIC_L2)  // the 4 norm loads were issued before this block's P >= RING ring re-arms
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-        park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
+        park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's clamped re-arms are still in flight
 }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void qprep_split_kernel(const float* __restric
     qf[npairs * 64 + idx] = lo;
 }
 
-template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0>
+template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1>
 __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P/2][64] hi fragments, then [P/2][64] lo fragments (16 B each)
@@ -400,9 +400,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);
     const float4* base = a.xb + b0 * P * kPieceVec4;
-    float mh[kChunk];  // lane maxima of the current chunk (shift chain)
+    float mh[kChunk], mh2[kChunk];  // lane maxima of the current chunk (shift chains; mh2 = second query tile)
 #pragma unroll
-    for (int t = 0; t < kChunk; ++t) mh[t] = 0.f;
+    for (int t = 0; t < kChunk; ++t) { mh[t] = 0.f; mh2[t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -423,7 +423,11 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         const bool vec_ok = (a.d & 3) == 0;
         for (int idx = tid; idx < npairs * 64; idx += NT) {
             const int pp = idx >> 6, l = idx & 63;
-            const int b = l & 31, hh = l >> 5;
+            const int hh = l >> 5;
+            unsigned hA[4], lA[4], hB[4];
+#pragma unroll
+            for (int tile = 0; tile < QT; ++tile) {
+            const int b = (l & 31) + 32 * tile;
             float v[8];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -442,8 +446,12 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             split_pair(v[2], v[3], h1, l1);
             split_pair(v[4], v[5], h2, l2);
             split_pair(v[6], v[7], h3, l3);
-            qhi_w[idx] = u32x4{h0, h1, h2, h3};
-            qlo_w[idx] = u32x4{l0, l1, l2, l3};
+            if (tile == 0) { hA[0] = h0; hA[1] = h1; hA[2] = h2; hA[3] = h3; lA[0] = l0; lA[1] = l1; lA[2] = l2; lA[3] = l3; }
+            else { hB[0] = h0; hB[1] = h1; hB[2] = h2; hB[3] = h3; }
+            }
+            qhi_w[idx] = u32x4{hA[0], hA[1], hA[2], hA[3]};
+            // second half of the tile: lo parts of queries 0..31 (QT == 1) or hi parts of queries 32..63 (QT == 2)
+            qlo_w[idx] = QT == 1 ? u32x4{lA[0], lA[1], lA[2], lA[3]} : u32x4{hB[0], hB[1], hB[2], hB[3]};
         }
     }
     __syncthreads();
@@ -483,9 +491,16 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
                 nx = nx == npairs ? 0 : nx;
                 bh_next = qhi[nx * 64 + lane];
                 bl_next = qlo[nx * 64 + lane];
-                acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc_hi, 0, 0, 0);
-                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_lo, 0, 0, 0);
-                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_lo, 0, 0, 0);
+                if (QT == 1) {  // 32 queries: hi*hi | hi*lo + lo*hi
+                    acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc_hi, 0, 0, 0);
+                    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_lo, 0, 0, 0);
+                    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_lo, 0, 0, 0);
+                } else {        // 64 queries, hi-only query fragments: (hi + lo of x) * hi of q, one accumulator per tile
+                    acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc_hi, 0, 0, 0);
+                    acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_hi, 0, 0, 0);
+                    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_lo, 0, 0, 0);
+                    acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc_lo, 0, 0, 0);
+                }
                 const unsigned voff0 = lane16 + (unsigned)min(s + RING + 2 * i, S - 1) * 1024u;
                 const unsigned voff1 = lane16 + (unsigned)min(s + RING + 2 * i + 1, S - 1) * 1024u;
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[2 * i]) : "v"(voff0), "s"(base) : "memory");
@@ -496,16 +511,21 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         }
         if (METRIC == HIPRAG_METRIC_L2)
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-        f32x16 acc;
+        if (QT == 1) {
+            f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = acc_hi[i] + acc_lo[i];
-        if (VARIANT == 20) {  // timing experiment: no group-max store at all
-            float t = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = acc_hi[i] + acc_lo[i];
+            if (VARIANT == 20) {  // timing experiment: no group-max store at all
+                float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t += acc[i];
-            if (t == 123.456f) a.gmax[0] = t;
+                for (int i = 0; i < 16; ++i) t += acc[i];
+                if (t == 123.456f) a.gmax[0] = t;
+            } else {
+                park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
+            }
         } else {
-            park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a);
+            park_and_flush(mh, block_lane_max<METRIC>(acc_hi, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
+            park_and_flush(mh2, block_lane_max<METRIC>(acc_lo, nrm, blk, h, a), blk, b0, b1, lane, a, 32);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -578,7 +598,7 @@ struct FinishArgs {
     i64* cand_i;
     double* qn2;                     // [nq]
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
-    int split;                 // scan used bf16 hi/lo split operands: eps gains the truncation term
+    int split;                 // scan operand mode: 0 exact fp32, 1 bf16 hi/lo split, 2 split x + hi-only queries (64/pass)
 };
 
 template <int METRIC>
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
                 const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
                 const double qn = sqrt(qn2);
                 const double u = 5.9604644775390625e-08;  // 2^-24
-                double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split ? 1.52587890625e-05 : 0.0)) * qn * xn;
+                double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split == 1 ? 1.52587890625e-05 : a.split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
                 double kth_sel;  // k-th exact score on the scale the scan selects by
                 if (METRIC == HIPRAG_METRIC_IP) {
                     kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
@@ -828,7 +848,7 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
             const double qn = sqrt(qn2);
             const double u = 5.9604644775390625e-08;  // 2^-24
             const int dpad = a.P * 8;
-            double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split ? 1.52587890625e-05 : 0.0)) * qn * xn;
+            double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split == 1 ? 1.52587890625e-05 : a.split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
             double kth_sel;
             if (METRIC == HIPRAG_METRIC_IP) {
                 kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
@@ -966,7 +986,7 @@ struct DenseIndex {
     int d = 0, P = 0, metric = 0;
     int64_t ntotal = 0, cap_blocks = 0, id_base = 0;
     int n_cu = 256;
-    bool split_mode = true;   // HIPRAG_SCAN_MODE=f32 selects the exact-fp32 MFMA scan (read once, at creation)
+    int scan_mode = 2;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo, 32 q/pass), q64 = 2 (default)
     int scan_variant = 0;     // HIPRAG_SCAN_VARIANT: timing experiments only
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
@@ -1000,7 +1020,7 @@ struct DenseIndex {
         HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const char* ms = getenv("HIPRAG_SCAN_MODE");
-        split_mode = !(ms && ms[0] == 'f');
+        if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
         const char* vs = getenv("HIPRAG_SCAN_VARIANT");
         scan_variant = vs ? atoi(vs) : 0;
         int32_t rc = scalars.reserve(64);
@@ -1071,7 +1091,9 @@ struct DenseIndex {
         return HIPRAG_OK;
     }
 
-    static int kprime(int k) { return k + kSlackGroups; }
+    int pass_queries() const { return scan_mode == 2 ? 64 : 32; }
+    // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
+    int kprime(int k) const { return scan_mode == 2 ? std::max(k + 22, 32) : k + kSlackGroups; }
 
     int32_t reserve_search(int k)
     {
@@ -1112,14 +1134,14 @@ struct DenseIndex {
         sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
         sa.gstride = ((2 * ws_blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
-        const bool split = split_mode;
-        w.split = split ? 1 : 0;
+        const bool split = scan_mode != 0;
+        w.split = scan_mode;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
-            const char* vs = getenv("HIPRAG_SCAN_VARIANT");  // timing experiments only
-            if (vs && atoi(vs) == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;
+            if (scan_mode == 2) scan = scan_split_kernel<METRIC, 8, 16, 0, 2>;          // 64 queries, hi-only query tiles
+            else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(8 * 64), scan_lds, st, sa);
@@ -1237,8 +1259,8 @@ struct DenseIndex {
     {
         int32_t rc = prepare(k);
         if (rc) return rc;
-        for (int o = 0; o < nq; o += kMaxQ) {
-            const int m = std::min(kMaxQ, nq - o);
+        for (int o = 0; o < nq; o += pass_queries()) {
+            const int m = std::min(pass_queries(), nq - o);
             const float* qo = q_dev + (int64_t)o * d;
             if ((rc = begin_dev(qo, m, 0, st))) return rc;
             if ((rc = finish_dev(qo, m, k, 0, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
@@ -1348,6 +1370,14 @@ int32_t hipidx_set_id_base(uint64_t h, int64_t id_base)
     return HIPRAG_OK;
 }
 
+int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_n, "null out");
+    *out_n = ix->pass_queries();
+    return HIPRAG_OK;
+}
+
 int32_t hipidx_reserve_search(uint64_t h, int32_t k)
 {
     GET_INDEX(h);
@@ -1369,7 +1399,7 @@ int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k,
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream)
 {
     GET_INDEX(h);
-    HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_begin takes 1..%d queries (got %d)", kMaxQ, nq);
+    HR_REQUIRE(nq > 0 && nq <= ix->pass_queries(), "search_begin takes 1..%d queries (got %d)", ix->pass_queries(), nq);
     HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
     HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     HR_REQUIRE(q_dev, "null device pointer");
@@ -1382,7 +1412,7 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
 {
     GET_INDEX(h);
-    HR_REQUIRE(nq > 0 && nq <= kMaxQ, "search_finish takes 1..%d queries (got %d)", kMaxQ, nq);
+    HR_REQUIRE(nq > 0 && nq <= ix->pass_queries(), "search_finish takes 1..%d queries (got %d)", ix->pass_queries(), nq);
     HR_REQUIRE(k > 0 && k <= ix->ws_k, "k=%d was not prepared by search_begin", k);
     HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");

@@ -118,6 +118,13 @@ class HipFlatIndex:
                  _stream_ptr() if stream is None else ctypes.c_void_p(stream))
         return out
 
+    @property
+    def pass_queries(self) -> int:
+        """Queries one scan pass serves (search_begin's limit): 64 by default, 32 in the split / f32 operand modes."""
+        n = ctypes.c_int32()
+        nat.call("hipidx_pass_queries", self._h, ctypes.byref(n))
+        return n.value
+
     def reserve_search(self, k: int) -> None:
         nat.call("hipidx_reserve_search", self._h, int(k))
 

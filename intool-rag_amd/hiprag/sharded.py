@@ -18,7 +18,6 @@ from typing import List, Tuple
 
 from .index import HipFlatIndex, merge_topk_device
 
-MAX_PASS = 32   # queries per scan pass (the N dimension of the MFMA tile)
 N_SLOTS = 8     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
 
 
@@ -51,6 +50,7 @@ class ShardedFlatIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         local.set_id_base(row_lo)
+        self.max_pass = local.pass_queries      # queries per scan pass (32 or 64, see hipidx_pass_queries)
         # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
         # the tail of batch i+1, which cannot start before scan i+1 ends
         self.side = [torch.cuda.Stream(device=local.device) for _ in range(N_SLOTS)]
@@ -79,12 +79,12 @@ class ShardedFlatIndex:
         return cache
 
     def search_begin(self, q, k: int):
-        """q: float32 CUDA tensor [nq <= 32, d] that stays valid until search_end.  Returns a ticket.  The result
+        """q: float32 CUDA tensor [nq <= max_pass, d] that stays valid until search_end.  Returns a ticket.  The result
         tensors handed out by search_end belong to the slot and are reused N_SLOTS passes later."""
         import torch
         nq = q.shape[0]
-        if nq > MAX_PASS:
-            raise ValueError(f"search_begin takes at most {MAX_PASS} queries; use search_device for larger batches")
+        if nq > self.max_pass:
+            raise ValueError(f"search_begin takes at most {self.max_pass} queries; use search_device for larger batches")
         slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
         c = self._buffers(slot, nq, k, q.device)
@@ -136,10 +136,10 @@ class ShardedFlatIndex:
         return self._bufs[slot]["fin" if work is not None else "done"]
 
     def search_device(self, q, k: int):
-        """Any number of queries; passes of 32 are pipelined internally."""
+        """Any number of queries; passes of max_pass queries are pipelined internally."""
         import torch
         nq = q.shape[0]
-        if nq <= MAX_PASS:
+        if nq <= self.max_pass:
             return self.search_end(self.search_begin(q, k))
         out = (torch.empty((nq, k), dtype=torch.float64, device=q.device),
                torch.empty((nq, k), dtype=torch.float32, device=q.device),
@@ -152,8 +152,8 @@ class ShardedFlatIndex:
             for dst, src in zip(out, res):
                 dst[o:o + src.shape[0]].copy_(src)
 
-        for o in range(0, nq, MAX_PASS):
-            pending.append((o, self.search_begin(q[o:o + MAX_PASS], k)))
+        for o in range(0, nq, self.max_pass):
+            pending.append((o, self.search_begin(q[o:o + self.max_pass], k)))
             if len(pending) >= N_SLOTS - 1:
                 drain()
         while pending:

@@ -214,3 +214,24 @@ def test_two_stream_pipeline_matches_oracle(gpu):
     s64b, s32b, idsb = sh.search_device(qd, k)
     torch.cuda.synchronize()
     assert np.array_equal(idsb.cpu().numpy(), ei)
+
+
+@pytest.mark.parametrize("mode", ["f32", "split", "q64"])
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mode, metric):
+    """HIPRAG_SCAN_MODE picks how candidates are generated (exact fp32 MFMA / bf16 hi-lo split / 64-query hi-only query
+    tiles); the certificate + fp64 re-score make the RESULT identical in every mode, including ties and a zero query."""
+    from hiprag import HipFlatIndex
+    monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
+    n, d, k = 7000, 512, 10
+    x = ho.synthetic_vectors(n, d, seed=81)
+    x[100:140] = x[5]                                    # 40 exact duplicates of row 5 spread over two blocks
+    q = ho.synthetic_queries(70, d, seed=82)
+    q[3] = x[5]
+    q[4] = 0
+    ix = HipFlatIndex(d, metric)
+    assert ix.pass_queries == (64 if mode == "q64" else 32)
+    ix.add(x)
+    _check(ix, x, q, k, metric)
+    _check(ix, x, q[:1], 50, metric)
+    assert ix.stats()["fallback_queries"] >= 1          # the zero query (and maybe the duplicate one) took the exhaustive path
