@@ -99,6 +99,8 @@ typedef struct hipidx_stats {
     int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
     int64_t timed_passes;      /* scan launches averaged into avg_scan_ms (at most the last 512) */
     float avg_scan_ms;         /* mean HIP-event duration of the scan kernel since timing was enabled, else -1 */
+    float avg_scan_wall_ms;    /* same launches on the GPU wall clock, stamped inside the kernel: first wave in -> last wave out */
+    float avg_scan_gap_ms;     /* mean idle time between consecutive timed scans (last wave out -> next first wave in) */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
 int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* HIP events around each scan launch, on its stream; get_stats syncs */

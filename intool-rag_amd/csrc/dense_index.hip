@@ -41,6 +41,7 @@ constexpr int kRowsPerBlock = 32;
 constexpr int kPieceFloats = 256;
 constexpr int kPieceVec4 = 64;
 constexpr int kMaxQ = 64;          // queries per pass: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
+constexpr int kMaxDPad = 1024;    // d_pad limit (the 128 KiB query tile of the scan)
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
 constexpr int kExRows = 1024;      // rows per workgroup in the exhaustive path (16 KiB of LDS: it must fit BESIDE a
@@ -148,10 +149,12 @@ struct ScanArgs {
     const float* q;       // [nq, d] row-major queries (split path builds its fragments in the scan prologue)
     const float* norms;   // [rows] squared norms (L2 only)
     float* gmax;          // [kMaxQ, gstride] group maxima: one per (block, lane half) = 16 rows, chunk-permuted
+    float* gmax2;         // same layout: the best quad maximum of the group's OTHER three quads (see block_lane_top2)
     int64_t gstride;
     int64_t nblocks;
     int64_t ntotal;
     int nq, d, P;
+    unsigned long long* stamps;  // timing only (else null): [waves][2] wall-clock ticks at wave entry / exit
 };
 
 // ---- group maxima -----------------------------------------------------------------------------------------------
@@ -183,9 +186,19 @@ __device__ __forceinline__ void group_decode(int64_t slot, int64_t bpw, int64_t 
     blk = cb + off - (h ? cnt : 0);
 }
 
-// max over this lane's 16 scores of block blk (L2: 2<x,q> - |x|^2; padded tail rows never compete)
+// A group's 16 rows are four QUADS of 4 consecutive rows (quad g = rows 8g + 4h + 0..3: 64 contiguous bytes of every
+// piece, the unit the fp64 re-score reads).  The scan keeps per group
+//   first  = the largest quad maximum, with the quad number g in its two low mantissa bits, and
+//   second = the largest quad maximum among the other three quads (tagged the same way, the tag unused),
+// so the finish re-scores ONE quad per selected group (16 KiB instead of 64 KiB) and `second` bounds the 12 rows it did
+// not read; a group whose `second` can still reach the top k gets its other quads re-scored as well (fin_final_kernel).
+// Replacing two mantissa bits moves a value by < 2^-21 |v|: the certificate's eps carries that term (kTagSlack).
+// L2: scores are 2<x,q> - |x|^2.  Padded tail rows get -FLT_MAX (finite, so the tag cannot turn it into a NaN).
+__device__ __forceinline__ float tag_quad(float v, unsigned g) { return __uint_as_float((__float_as_uint(v) & ~3u) | g); }
+
 template <int METRIC>
-__device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (&nrm)[4], int64_t blk, int h, const ScanArgs& a)
+__device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 (&nrm)[4], int64_t blk, int h, const ScanArgs& a,
+                                                 float& second)
 {
     float sc[16];
     if (METRIC == HIPRAG_METRIC_L2) {
@@ -204,11 +217,20 @@ __device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t row = blk * kRowsPerBlock + 8 * (i >> 2) + 4 * h + (i & 3);
-            if (row >= a.ntotal) sc[i] = -INFINITY;
+            if (row >= a.ntotal) sc[i] = -FLT_MAX;
         }
     }
-    return fmaxf(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))),
-                 fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+    float qm[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        qm[g] = tag_quad(fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])), (unsigned)g);
+    float m1 = fmaxf(qm[0], qm[1]), m2 = fminf(qm[0], qm[1]);
+    m2 = __builtin_amdgcn_fmed3f(m1, m2, qm[2]);   // new runner-up = median(best, runner-up, newcomer)
+    m1 = fmaxf(m1, qm[2]);
+    m2 = __builtin_amdgcn_fmed3f(m1, m2, qm[3]);
+    m1 = fmaxf(m1, qm[3]);
+    second = m2;
+    return m1;
 }
 
 // Park one block's lane maximum in a 16-register shift chain (mh[0] = newest); on the last block of a chunk (or of the
@@ -217,7 +239,7 @@ __device__ __forceinline__ float block_lane_max(const f32x16& acc, const f32x4 (
 // workgroup.  Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
 // make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
 __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int64_t blk, int64_t b0, int64_t b1, int lane,
-                                               const ScanArgs& a, int qoff)
+                                               float* __restrict__ gm, int64_t gstride, int qoff)
 {
 #pragma unroll
     for (int t = kChunk - 1; t > 0; --t) mh[t] = mh[t - 1];
@@ -227,7 +249,7 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
     const int cnt = j + 1;
     const int64_t cb = blk - j;
     const int h = lane >> 5, qb = (lane & 31) + qoff;
-    float* dst = a.gmax + (int64_t)qb * a.gstride + 2 * cb + (int64_t)h * cnt;
+    float* dst = gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * cnt;
     if (cnt == kChunk) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)   // block cb + t sits in mh[15 - t]
@@ -257,10 +279,11 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
     const int64_t b0 = min(gw * bpw, a.nblocks);
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);  // pieces in this wave's stream
+    if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();
     const float4* base = a.xb + b0 * P * kPieceVec4;  // wave-uniform; lanes add 16 B each through the VGPR offset
-    float mh[kChunk];  // lane maxima of the current chunk (shift chain)
+    float mh[kChunk], ms[kChunk];  // lane first / second values of the current chunk (shift chains)
 #pragma unroll
-    for (int t = 0; t < kChunk; ++t) mh[t] = 0.f;
+    for (int t = 0; t < kChunk; ++t) { mh[t] = 0.f; ms[t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -280,7 +303,10 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
 
     for (int idx = tid; idx < P * kPieceVec4; idx += NT) qs[idx] = a.qf[idx];
     __syncthreads();
-    if (S <= 0) return;
+    if (S <= 0) {
+        if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
+        return;
+    }
 
     int s = 0;
     float4 bnext = qs[lane];
@@ -323,9 +349,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
         }
         if (METRIC == HIPRAG_METRIC_L2)  // the 4 norm loads were issued before this block's P >= RING ring re-arms
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-        park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
+        float sec;
+        const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
+        park_and_flush(mh, fst, blk, b0, b1, lane, a.gmax, a.gstride, 0);
+        park_and_flush(ms, sec, blk, b0, b1, lane, a.gmax2, a.gstride, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's clamped re-arms are still in flight
+    if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -400,9 +430,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const int64_t b1 = min(b0 + bpw, a.nblocks);
     const int S = (int)((b1 - b0) * P);
     const float4* base = a.xb + b0 * P * kPieceVec4;
-    float mh[kChunk], mh2[kChunk];  // lane maxima of the current chunk (shift chains; mh2 = second query tile)
+    if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();
+    // lane first / second values of the current chunk (shift chains); index = query tile
+    float mh[QT][kChunk], ms[QT][kChunk];
 #pragma unroll
-    for (int t = 0; t < kChunk; ++t) { mh[t] = 0.f; mh2[t] = 0.f; }
+    for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+        for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; ms[u][t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -455,7 +489,10 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         }
     }
     __syncthreads();
-    if (S <= 0) return;
+    if (S <= 0) {
+        if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
+        return;
+    }
 
     const bf16x8* qhi = reinterpret_cast<const bf16x8*>(qs);
     const bf16x8* qlo = qhi + npairs * 64;
@@ -521,14 +558,23 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
                 for (int i = 0; i < 16; ++i) t += acc[i];
                 if (t == 123.456f) a.gmax[0] = t;
             } else {
-                park_and_flush(mh, block_lane_max<METRIC>(acc, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
+                float sec;
+                const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
+                park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, 0);
+                park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 0);
             }
         } else {
-            park_and_flush(mh, block_lane_max<METRIC>(acc_hi, nrm, blk, h, a), blk, b0, b1, lane, a, 0);
-            park_and_flush(mh2, block_lane_max<METRIC>(acc_lo, nrm, blk, h, a), blk, b0, b1, lane, a, 32);
+            float sec;
+            float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h, a, sec);
+            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, 0);
+            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 0);
+            fst = block_lane_top2<METRIC>(acc_lo, nrm, blk, h, a, sec);
+            park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane, a.gmax, a.gstride, 32);
+            park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 32);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -597,9 +643,35 @@ struct FinishArgs {
     u64* cand_k;                     // [nq, 1024] re-scored candidates
     i64* cand_i;
     double* qn2;                     // [nq]
+    float* sec;                      // [nq, 64] `second` of every selected group (fin_rescore -> fin_final)
+    const float* gmax2;              // the scan's second-value array, gstride floats per query
+    int64_t gstride;
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
     int split;                 // scan operand mode: 0 exact fp32, 1 bf16 hi/lo split, 2 split x + hi-only queries (64/pass)
 };
+
+// Certificate slack: |scan value - exact score| <= eps for every row, on the scale the scan selects by (IP: <x,q>;
+// L2: 2<x,q> - |x|^2 = |q|^2 - dist).  Terms: fp32 accumulation ((d_pad + 2) u, u = 2^-24; + 80 u for the bf16 split's
+// extra roundings), the dropped lo*lo products of the split (2^-16), the hi-only query tiles of the 64-query mode
+// (1.97e-3 ~ 2^-9), and the quad tag in the two low mantissa bits (kTagSlack of the value's magnitude).
+constexpr double kTagSlack = 4.76837158203125e-07;  // 2^-21
+template <int METRIC>
+__device__ __forceinline__ double scan_eps(int dpad, int split, double qn2, double xn2)
+{
+    const double xn = sqrt(xn2), qn = sqrt(qn2);
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    double eps = (1.05 * (double)(dpad + (split ? 80 : 2)) * u + (split == 1 ? 1.52587890625e-05 : split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
+    if (METRIC == HIPRAG_METRIC_IP) return eps + kTagSlack * (qn * xn + eps);
+    eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn) + 4.0 * u * qn2;  // 2 * acc - norm, and the rounding of |q|^2 - dist
+    return eps + kTagSlack * (2.0 * qn * xn + xn * xn + eps);
+}
+// k-th exact score (ordered key) on the scan's scale; -inf while fewer than k rows are known
+template <int METRIC>
+__device__ __forceinline__ double kth_on_scan_scale(u64 kth_key, double qn2)
+{
+    if (kth_key == 0) return -INFINITY;
+    return METRIC == HIPRAG_METRIC_IP ? unord64(kth_key) : qn2 - (-unord64(kth_key));
+}
 
 template <int METRIC>
 __device__ __forceinline__ void write_result(double* out64, float* out32, int64_t* out_ids, int64_t o, u64 key, i64 id,
@@ -694,20 +766,9 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
         const u64 bk = selk[a.Kp];  // best group NOT re-scored
         if (bk != 0) {
             const float m = unord32((u32)(bk >> 32));
-            if (m != -INFINITY) {
-                const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
-                const double qn = sqrt(qn2);
-                const double u = 5.9604644775390625e-08;  // 2^-24
-                double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split == 1 ? 1.52587890625e-05 : a.split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
-                double kth_sel;  // k-th exact score on the scale the scan selects by
-                if (METRIC == HIPRAG_METRIC_IP) {
-                    kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
-                } else {
-                    eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
-                    kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;  // 2<x,q> - |x|^2 = |q|^2 - dist
-                    eps += 4.0 * u * qn2;                                        // rounding of qn2 - dist itself
-                }
-                if (!(kth_sel > (double)m + eps)) flag = 1;
+            if (m > -1.0e38f) {  // below that: padding only, every real row was re-scored
+                const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits));
+                if (!(kth_on_scan_scale<METRIC>(kth_key, qn2) > (double)m + eps)) flag = 1;
             }
         }
         a.flags[q] = flag;
@@ -728,7 +789,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
 // All three fit beside a resident scan workgroup (<= 10 KiB LDS).
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFinWaves = 16;
-constexpr int kCandPerQuery = 1024;  // 64 group slots x 16 rows
+constexpr int kCandPerQuery = 256;   // 64 group slots x the 4 rows of the tagged quad
 
 template <int NPL, int NW>
 __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
@@ -785,79 +846,111 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     }
 }
 
-// grid (K', nq), 256 threads: wave g of workgroup (j, q) re-scores rows 8g + 4h + 0..3 of selected group j
+// grid (ceil(K'/4), nq), 256 threads: wave w re-scores the tagged quad (4 rows) of selected group j = 4 * blockIdx.x + w
 template <int METRIC>
 __global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
 {
     extern __shared__ float qv[];  // d_pad floats (4 KiB: fits beside a resident scan workgroup)
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
-    const int j = blockIdx.x, q = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int j = blockIdx.x * 4 + (tid >> 6), q = blockIdx.y;
     const int dpad = a.P * 8;
     for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
     __syncthreads();
+    if (j >= a.Kp) return;
     const u64 e = a.sel[(int64_t)q * 64 + j];
     u64 key = 0;
     i64 row = -1;
+    float sec = -FLT_MAX;
     if (e != 0) {
+        const i64 slot = (i64)packed_index(e);
+        const int g = (int)(__float_as_uint(packed_value(e)) & 3u);
         int64_t blk;
         int gh;
-        group_decode((i64)packed_index(e), a.bpw, a.nblocks, blk, gh);
+        group_decode(slot, a.bpw, a.nblocks, blk, gh);
         const int r0 = 8 * g + 4 * gh;
         const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
         row = blk * kRowsPerBlock + r0 + (lane & 3);
         if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+        sec = a.gmax2[(int64_t)q * a.gstride + slot];
     }
     if (lane < 4) {
-        const int64_t o = (int64_t)q * kCandPerQuery + j * 16 + g * 4 + lane;
+        const int64_t o = (int64_t)q * kCandPerQuery + j * 4 + lane;
         a.cand_k[o] = key;
         a.cand_i[o] = row;
     }
+    if (lane == 0) a.sec[(int64_t)q * 64 + j] = sec;
 }
 
+// one wave per query: exact top-k of the 4 K' re-scored rows under (score, id); then every selected group whose `second`
+// could still reach the k-th score gets its other three quads re-scored here (about one query in a thousand has one);
+// then the certificate against the best group that was not selected.
 template <int METRIC>
 __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
 {
+    __shared__ float qv[kMaxDPad];  // staged only when a group needs its other quads
     const int q = blockIdx.x, lane = threadIdx.x;
-    const int ncand = a.Kp * 16;
+    const int ncand = a.Kp * 4;
     const u64* ck = a.cand_k + (int64_t)q * kCandPerQuery;
     const i64* ci = a.cand_i + (int64_t)q * kCandPerQuery;
-    u64 ckc[16];
-    i64 cic[16];
+    u64 ckc[4];
+    i64 cic[4];
     u64 m = 0;
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < 4; ++n) {
         const int i = n * 64 + lane;
         ckc[n] = i < ncand ? ck[i] : 0ull;
         cic[n] = i < ncand ? ci[i] : -1;
         m = ckc[n] > m ? ckc[n] : m;
     }
+    const u64 e_l = a.sel[(int64_t)q * 64 + lane];                       // lanes 0..K' hold the selected groups
+    const float m2_l = lane < a.Kp ? a.sec[(int64_t)q * 64 + lane] : -FLT_MAX;
+    const double qn2 = a.qn2[q];
+    const int dpad = a.P * 8;
+    const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits));
+
     const u64 t0 = wave_kth_of_lanes(m, a.k);   // k lanes hold a key >= t0: nothing below t0 can reach the top k
     WaveListPair F;
     F.init();
 #pragma unroll
-    for (int n = 0; n < 16; ++n) F.offer(ckc[n] >= t0 ? ckc[n] : 0ull, cic[n], a.k);
+    for (int n = 0; n < 4; ++n) F.offer(ckc[n] >= t0 ? ckc[n] : 0ull, cic[n], a.k);
+
+    unsigned long long done = 0;
+    bool staged = false;
+    for (;;) {
+        const double kth = kth_on_scan_scale<METRIC>(readlane_u64(F.k, a.k - 1), qn2);
+        const bool need = lane < a.Kp && e_l != 0 && m2_l > -1.0e38f && !(kth > (double)m2_l + eps);
+        const unsigned long long mask = __ballot(need) & ~done;
+        if (!mask) break;
+        const int j = __builtin_ctzll(mask);
+        done |= 1ull << j;
+        if (!staged) {
+            for (int c = lane; c < dpad; c += 64) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+            __syncthreads();
+            staged = true;
+        }
+        const u64 e = readlane_u64(e_l, j);
+        const int tagged = (int)(__float_as_uint(packed_value(e)) & 3u);
+        int64_t blk;
+        int gh;
+        group_decode((i64)packed_index(e), a.bpw, a.nblocks, blk, gh);
+        for (int g = 0; g < 4; ++g) {
+            if (g == tagged) continue;
+            const int r0 = 8 * g + 4 * gh;
+            const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+            const i64 row = blk * kRowsPerBlock + r0 + (lane & 3);
+            const u64 key = (lane < 4 && row < a.ntotal) ? ord64(METRIC == HIPRAG_METRIC_IP ? s : -s) : 0ull;
+            F.offer(key, row, a.k);
+        }
+    }
+
     if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
     const u64 kth_key = readlane_u64(F.k, a.k - 1);
+    const u64 bk = readlane_u64(e_l, a.Kp);  // best group NOT selected
     if (lane == 0) {
         int flag = 0;
-        const u64 bk = a.sel[(int64_t)q * 64 + a.Kp];  // best group NOT re-scored
         if (bk != 0) {
             const float m32 = packed_value(bk);
-            const double qn2 = a.qn2[q];
-            const double xn = sqrt((double)__uint_as_float(*a.max_norm2_bits));
-            const double qn = sqrt(qn2);
-            const double u = 5.9604644775390625e-08;  // 2^-24
-            const int dpad = a.P * 8;
-            double eps = (1.05 * (double)(dpad + (a.split ? 80 : 2)) * u + (a.split == 1 ? 1.52587890625e-05 : a.split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
-            double kth_sel;
-            if (METRIC == HIPRAG_METRIC_IP) {
-                kth_sel = kth_key ? unord64(kth_key) : -INFINITY;
-            } else {
-                eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn);
-                kth_sel = kth_key ? qn2 - (-unord64(kth_key)) : -INFINITY;
-                eps += 4.0 * u * qn2;
-            }
-            if (!(kth_sel > (double)m32 + eps)) flag = 1;
+            if (m32 > -1.0e38f && !(kth_on_scan_scale<METRIC>(kth_key, qn2) > (double)m32 + eps)) flag = 1;
         }
         a.flags[q] = flag;
         a.arrivals[q] = 0;
@@ -1002,6 +1095,8 @@ struct DenseIndex {
     static constexpr int kEvRing = 512;
     bool timing = false;
     std::vector<hipEvent_t> evs;   // 2*kEvRing once timing was enabled
+    DevBuf stamps;                 // [kEvRing][n_cu * 8 waves][2] in-kernel wall-clock ticks of the same launches
+    int wall_khz = 100000;
     int64_t ev_count = 0;          // pairs recorded since timing was (re)enabled
 
     int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
@@ -1109,13 +1204,13 @@ struct DenseIndex {
         const int64_t nlists = std::max(nchunks, ((gstride + kSelPerWave - 1) / kSelPerWave + 3) / 4 * 4);
         for (Workspace& w : ws) {
             int32_t rc;
-            if ((rc = w.gmax.reserve((size_t)kMaxQ * gstride * sizeof(float)))) return rc;
+            if ((rc = w.gmax.reserve((size_t)2 * kMaxQ * gstride * sizeof(float)))) return rc;  // first | second
             if ((rc = w.qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
             if ((rc = w.ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
             if ((rc = w.ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
             if ((rc = w.flags.reserve(2 * kMaxQ * sizeof(int)))) return rc;  // flags[kMaxQ] + arrivals[kMaxQ]
-            // sel[kMaxQ][64] u64 | cand_k[kMaxQ][1024] u64 | cand_i[kMaxQ][1024] i64 | qn2[kMaxQ] f64
-            if ((rc = w.fin.reserve((size_t)kMaxQ * (64 + 2 * kCandPerQuery + 1) * 8))) return rc;
+            // sel[kMaxQ][64] u64 | cand_k[kMaxQ][256] u64 | cand_i[kMaxQ][256] i64 | qn2[kMaxQ] f64 | sec[kMaxQ][64] f32
+            if ((rc = w.fin.reserve((size_t)kMaxQ * (64 + 2 * kCandPerQuery + 1 + 32) * 8))) return rc;
             if ((rc = w.ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
             if ((rc = w.ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
         }
@@ -1132,12 +1227,14 @@ struct DenseIndex {
         const int64_t nb = nblocks();
         ScanArgs sa;
         sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
+        sa.gmax2 = sa.gmax + (size_t)kMaxQ * (((2 * ws_blocks + 3) / 4) * 4);
         sa.gstride = ((2 * ws_blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = scan_mode != 0;
         w.split = scan_mode;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
+        sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * 8 * 2 : nullptr;
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
             if (scan_mode == 2) scan = scan_split_kernel<METRIC, 8, 16, 0, 2>;          // 64 queries, hi-only query tiles
@@ -1196,13 +1293,16 @@ struct DenseIndex {
             fa.cand_k = fin_base + (size_t)kMaxQ * 64;
             fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)kMaxQ * kCandPerQuery);
             fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)kMaxQ * kCandPerQuery);
+            fa.sec = reinterpret_cast<float*>(fa.qn2 + kMaxQ);
+            fa.gmax2 = w.gmax.as<float>() + (size_t)kMaxQ * gstride;
+            fa.gstride = gstride;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 256) hipLaunchKernelGGL((fin_merge_kernel<4, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 512) hipLaunchKernelGGL((fin_merge_kernel<8, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 2048) hipLaunchKernelGGL((fin_merge_kernel<8, 4>), dim3(nq), dim3(256), 0, st, fa);
             else hipLaunchKernelGGL((fin_merge_kernel<16, 16>), dim3(nq), dim3(1024), 0, st, fa);
-            hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3(Kp, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
+            hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3((Kp + 3) / 4, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
             hipLaunchKernelGGL(fin_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, fa);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
             hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(64), 0, st, flags, arrivals, fallback_counter(), nq);
@@ -1239,6 +1339,10 @@ struct DenseIndex {
         if (timing && evs.empty()) {
             evs.resize(2 * kEvRing);
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
+            int32_t src = stamps.reserve((size_t)kEvRing * n_cu * 8 * 2 * sizeof(unsigned long long));
+            if (src) return src;
+            (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device);
+            if (wall_khz <= 0) wall_khz = 100000;
         }
         return HIPRAG_OK;
     }
@@ -1548,6 +1652,8 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
     out->bytes_per_pass = ix->nblocks() * ix->P * 1024 +
                           (ix->metric == HIPRAG_METRIC_L2 ? ix->nblocks() * kRowsPerBlock * 4 : 0);
     out->avg_scan_ms = -1.f;
+    out->avg_scan_wall_ms = -1.f;
+    out->avg_scan_gap_ms = 0.f;
     out->timed_passes = 0;
     if (!ix->evs.empty() && ix->ev_count > 0) {
         const int64_t n = std::min<int64_t>(ix->ev_count, DenseIndex::kEvRing);
@@ -1558,6 +1664,35 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             if (hipEventElapsedTime(&ms, ix->evs[2 * i], ix->evs[2 * i + 1]) == hipSuccess) { sum += ms; ++ok; }
         }
         if (ok) { out->avg_scan_ms = (float)(sum / ok); out->timed_passes = ok; }
+        // the same launches on the GPU's own wall clock: first wave in -> last wave out, and the idle time between the
+        // last wave of one scan and the first wave of the next (negative = the next scan started on CUs already free)
+        if (ix->stamps.p && ix->nblocks() > 0) {
+            const size_t per = (size_t)ix->n_cu * 8 * 2;
+            std::vector<unsigned long long> hst((size_t)n * per);
+            HR_CHECK_HIP(hipMemcpy(hst.data(), ix->stamps.p, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<std::pair<unsigned long long, unsigned long long>> se((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                unsigned long long lo = ~0ull, hi = 0;
+                for (size_t w = 0; w < per / 2; ++w) {
+                    lo = std::min(lo, hst[(size_t)i * per + 2 * w]);
+                    hi = std::max(hi, hst[(size_t)i * per + 2 * w + 1]);
+                }
+                se[(size_t)i] = {lo, hi};
+            }
+            double dsum = 0.0, gsum = 0.0;
+            for (int64_t i = 0; i < n; ++i) dsum += (double)(se[(size_t)i].second - se[(size_t)i].first);
+            const bool ordered = ix->ev_count <= DenseIndex::kEvRing;
+            for (int64_t i = 0; ordered && i + 1 < n; ++i) gsum += (double)((long long)se[(size_t)i + 1].first - (long long)se[(size_t)i].second);
+            if (getenv("HIPRAG_DEBUG_GAPS") && ordered) {
+                fprintf(stderr, "[hiprag] scan wall us / gap-to-next us:");
+                for (int64_t i = 40; i < std::min<int64_t>(n - 1, 72); ++i)
+                    fprintf(stderr, " %.0f/%.0f", (double)(se[(size_t)i].second - se[(size_t)i].first) * 1e3 / ix->wall_khz,
+                            (double)((long long)se[(size_t)i + 1].first - (long long)se[(size_t)i].second) * 1e3 / ix->wall_khz);
+                fprintf(stderr, "\n");
+            }
+            out->avg_scan_wall_ms = (float)(dsum / n / ix->wall_khz);
+            out->avg_scan_gap_ms = ordered && n > 1 ? (float)(gsum / (n - 1) / ix->wall_khz) : 0.f;
+        }
         if (getenv("HIPRAG_DEBUG_GAPS") && ix->ev_count <= DenseIndex::kEvRing) {
             double gsum = 0.0; int64_t gn = 0;
             for (int64_t i = 0; i + 1 < n; ++i) {

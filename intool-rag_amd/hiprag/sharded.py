@@ -14,6 +14,7 @@ the scan of batch i+1.  `search_end` makes the caller's stream wait for the batc
 """
 from __future__ import annotations
 
+import os
 from typing import List, Tuple
 
 from .index import HipFlatIndex, merge_topk_device
@@ -59,6 +60,7 @@ class ShardedFlatIndex:
         self._slot_used = [False] * N_SLOTS
         self._slot_ended = [False] * N_SLOTS
         self._bufs = [dict() for _ in range(N_SLOTS)]
+        self._scan_done = [torch.cuda.Event() for _ in range(N_SLOTS)]
 
     def _buffers(self, slot: int, nq: int, k: int, dev):
         """Per-slot result buffers and events, created once per (nq, k): the steady state allocates nothing."""
@@ -88,17 +90,31 @@ class ShardedFlatIndex:
         slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
         c = self._buffers(slot, nq, k, q.device)
-        if self._slot_used[slot] and not self._slot_ended[slot]:
-            # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
-            # waited there and stream order covers it (one barrier packet less per step)
-            main.wait_event(c["fin"] if self.world > 1 else c["done"])
-        self._slot_used[slot] = True
-        self._slot_ended[slot] = False
+        # The whole pass -- scan, selection, re-score, exchange -- runs on the slot's own stream: consecutive passes sit
+        # in different hardware queues with no dependency between them, so the next scan's workgroups take over the
+        # CUs as the previous scan's drain (a scan chained behind its predecessor on one stream pays a dependent-dispatch
+        # bubble of tens of microseconds per pass).  Stream order on `side` also covers slot reuse.
         side = self.side[slot]
         pack = c["pack"]
-        self.local.search_begin(q, k, slot, stream=main.cuda_stream)
-        c["scanned"].record(main)
-        side.wait_event(c["scanned"])
+        if os.environ.get("HIPRAG_SCAN_ON_MAIN") == "1":
+            if self._slot_used[slot] and not self._slot_ended[slot]:
+                main.wait_event(c["fin"] if self.world > 1 else c["done"])
+            self.local.search_begin(q, k, slot, stream=main.cuda_stream)
+            c["scanned"].record(main)
+            side.wait_event(c["scanned"])
+        else:
+            c["scanned"].record(main)          # q was produced on the caller's stream
+            side.wait_event(c["scanned"])
+            # at most ONE scan waits behind the running one: two scans released together would share the CUs and both
+            # finish late.  Scan i is released when scan i-2 completes, i.e. while scan i-1 runs, so the wait is hidden.
+            lag = int(os.environ.get("HIPRAG_SCAN_LAG", "2"))
+            before = (slot - lag) % N_SLOTS
+            if lag > 0 and self._slot_used[before]:
+                side.wait_event(self._scan_done[before])
+            self.local.search_begin(q, k, slot, stream=self._side_ptr[slot])
+            self._scan_done[slot].record(side)
+        self._slot_used[slot] = True
+        self._slot_ended[slot] = False
         self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=self._side_ptr[slot])
         c["done"].record(side)
         work = None
