@@ -102,10 +102,13 @@ def main():
     gq.manual_seed(4321)
     queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
     queries /= queries.norm(dim=1, keepdim=True)
-    BATCH = index.pass_queries          # one scan pass per step: 64 queries (32 with HIPRAG_SCAN_MODE=split|f32)
+    # one scan LAUNCH per step: 256 queries = 4 passes of 64 run back to back inside the launch (each pass streams the
+    # local rows once for its own query tile); HIPRAG_LAUNCH_QUERIES / HIPRAG_SCAN_MODE change the split
+    BATCH = index.launch_queries
+    PASSES = (BATCH + index.pass_queries - 1) // index.pass_queries
     nb = N_QUERIES // BATCH
 
-    IN_FLIGHT = 6      # steps in flight (the library has 8 workspace slots); results are consumed in order
+    IN_FLIGHT = 4      # steps in flight (the library has 8 workspace slots); results are consumed in order
 
     def run_steps(n, first):
         """n pipelined steps: while step i scans, the tails (select / re-score / all-gather / merge) of the previous
@@ -140,11 +143,11 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        scan = torch.tensor([st["avg_scan_ms"]], dtype=torch.float64, device=dev)
+        scan = torch.tensor([st["avg_scan_ms"], st["avg_scan_wall_ms"]], dtype=torch.float64, device=dev)
         dist.all_reduce(scan, op=dist.ReduceOp.MAX)
-        scan_ms = float(scan.item())
+        scan_ms, wall_ms = float(scan[0].item()), float(scan[1].item())
     else:
-        scan_ms = float(st["avg_scan_ms"])
+        scan_ms, wall_ms = float(st["avg_scan_ms"]), float(st["avg_scan_wall_ms"])
 
     # ---- p50 latency of single queries through the host boundary (python -> C-ABI -> sync) -----------
     lat = []
@@ -164,7 +167,8 @@ def main():
         return
 
     qps = args.steps * BATCH / elapsed
-    bytes_per_launch = int(st["bytes_per_pass"])           # local rows * d_pad * 4: what ONE scan launch streams
+    # local rows * d_pad * 4 per pass, PASSES passes per launch: what ONE scan launch streams
+    bytes_per_launch = int(st["bytes_per_pass"]) * PASSES
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {
         "metric": "queries/sec, exact top-10 inner-product search, 1M x 1024-d fp32 index",
@@ -180,7 +184,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
-                   "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH,
+                   "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH, "passes_per_step": PASSES,
+                   "queries_per_pass": index.pass_queries,
                    "sharding": f"rows/{world}" if world > 1 else "none",
                    "exchange": f"1 all-gather of [2,{BATCH},{TOPK}] int64 per step" if world > 1 else "none",
                    "steps_in_flight": IN_FLIGHT},
@@ -188,10 +193,11 @@ def main():
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "fallback_queries": int(st["fallback_queries"]),
         "build_s": round(build_s, 2),
-        "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "scan_split_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
-                     "launches_timed": int(st["timed_passes"])},
+                     "bytes_per_launch": bytes_per_launch, "passes_per_launch": PASSES,
+                     "avg_launch_ms": round(scan_ms, 5), "launches_timed": int(st["timed_passes"]),
+                     "avg_launch_ms_gpu_clock": round(wall_ms, 5), "avg_gap_ms_between_launches": round(float(st["avg_scan_gap_ms"]), 5)},
     }
 
     # ---- CPU baseline: the oracle's reference-faithful twin, bounded sample, rank 0, N=1 only ----------

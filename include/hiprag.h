@@ -79,28 +79,34 @@ int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k,
  * tiles), 32 with HIPRAG_SCAN_MODE=split (hi/lo on both sides) or =f32 (exact fp32 MFMA).  All modes return the same
  * exact results; they differ in how wide the certificate's error bound is and how many rows get re-scored. */
 int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n);
-/* Two-phase form of one pass (nq <= hipidx_pass_queries) for callers that pipeline: begin = query fragments + index scan into
- * workspace `slot` (0..7); finish = group selection, fp64 re-score, top-k, certificate / fallback out of that slot.
- * begin(slot s) of a later pass must be ordered after finish(slot s) of the pass that used it (stream order or an event); the two phases
- * of one pass may run on different streams if finish waits for begin.  search_dev == begin + finish on slot 0. */
+/* Queries one scan LAUNCH takes (default 256, HIPRAG_LAUNCH_QUERIES; a multiple of the pass size): the scan kernel runs
+ * launch/pass passes back to back inside one launch -- each pass streams the index once for its own query tile -- so
+ * that no kernel boundary (35-45 us of idle GPU) separates them.  The exact-fp32 mode runs one pass per launch. */
+int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
+/* Two-phase form of one launch (nq <= hipidx_launch_queries) for callers that pipeline: begin = index scan into
+ * workspace `slot` (0..7, allocated on first use); finish = group selection, fp64 re-score, top-k, certificate /
+ * fallback out of that slot.  begin(slot s) of a later call must be ordered after finish(slot s) of the call that
+ * used it (stream order or an event); the two phases may run on different streams if finish waits for begin.
+ * search_dev == begin + finish on slot 0, repeated for every hipidx_launch_queries queries. */
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);
 int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* make sure search workspace for (nq<=32 per pass, k) exists so that search_dev never allocates */
+/* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);
 int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host); /* row as stored (tests, export) */
 int32_t hipidx_save(uint64_t h, const char* path);
 int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle);
 
 typedef struct hipidx_stats {
-    int64_t passes;            /* scan launches so far (one per <=32 queries) */
+    int64_t passes;            /* scan passes so far (one per <= pass_queries queries; several per launch) */
     int64_t queries;           /* queries answered */
     int64_t fallback_queries;  /* queries whose fast-path certificate failed and took the exhaustive path */
     int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
-    int64_t timed_passes;      /* scan launches averaged into avg_scan_ms (at most the last 512) */
+    int64_t timed_passes;      /* scan LAUNCHES averaged into avg_scan_ms (at most the last 512) */
     float avg_scan_ms;         /* mean HIP-event duration of the scan kernel since timing was enabled, else -1 */
     float avg_scan_wall_ms;    /* same launches on the GPU wall clock, stamped inside the kernel: first wave in -> last wave out */
     float avg_scan_gap_ms;     /* mean idle time between consecutive timed scans (last wave out -> next first wave in) */
+    int64_t launches;          /* scan kernel launches so far (each runs 1..launch_queries/pass_queries passes back to back) */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
 int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* HIP events around each scan launch, on its stream; get_stats syncs */

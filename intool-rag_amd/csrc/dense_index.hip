@@ -40,7 +40,8 @@ namespace {
 constexpr int kRowsPerBlock = 32;
 constexpr int kPieceFloats = 256;
 constexpr int kPieceVec4 = 64;
-constexpr int kMaxQ = 64;          // queries per pass: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
+// a PASS = the queries that share one read of the index: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
+constexpr int kMaxQ = 256;         // queries per LAUNCH: the split scans run up to kMaxQ / pass queries passes back to back
 constexpr int kMaxDPad = 1024;    // d_pad limit (the 128 KiB query tile of the scan)
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
@@ -164,7 +165,7 @@ struct ScanArgs {
 // one float per lane it is nearly free.  Each wave parks its lane maxima in LDS ([16 blocks][64 lanes]) and every 16
 // blocks each lane writes its 16 values as one 64-B run, so a query's (h = 0, h = 1) pair fills a whole 128-B line:
 //   slot of (block cb + j of a chunk of cnt blocks starting at cb, half h) = 2*cb + h*cnt + j      (see group_decode)
-constexpr int kChunk = 16;
+constexpr int kChunk = 16;        // blocks per flush of the fp32 scan and the default of the split scans (template CH)
 
 __host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks, int64_t nwaves)
 {
@@ -173,14 +174,14 @@ __host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks
 }
 
 // slot -> (block, lane half); inverse of the permutation above.  bpw = scan_blocks_per_wave(nblocks, waves of the scan).
-__device__ __forceinline__ void group_decode(int64_t slot, int64_t bpw, int64_t nblocks, int64_t& blk, int& h)
+__device__ __forceinline__ void group_decode(int64_t slot, int64_t bpw, int64_t nblocks, int chunk, int64_t& blk, int& h)
 {
     const int64_t bq = slot >> 1;                      // lies inside the same chunk as the group's block
     const int64_t b0 = (bq / bpw) * bpw;
-    const int64_t cb = b0 + ((bq - b0) / kChunk) * kChunk;
+    const int64_t cb = b0 + ((bq - b0) / chunk) * chunk;
     int64_t end = b0 + bpw;
     if (end > nblocks) end = nblocks;
-    const int64_t cnt = end - cb < kChunk ? end - cb : kChunk;
+    const int64_t cnt = end - cb < chunk ? end - cb : chunk;
     const int64_t off = slot - 2 * cb;
     h = off >= cnt ? 1 : 0;
     blk = cb + off - (h ? cnt : 0);
@@ -238,6 +239,7 @@ __device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 
 // the remaining 32 KiB must stay free so that the tail kernels of earlier passes can be co-resident with a scan
 // workgroup.  Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
 // make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
+template <int kChunk>
 __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int64_t blk, int64_t b0, int64_t b1, int lane,
                                                float* __restrict__ gm, int64_t gstride, int qoff)
 {
@@ -252,8 +254,9 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
     float* dst = gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * cnt;
     if (cnt == kChunk) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v)   // block cb + t sits in mh[15 - t]
-            reinterpret_cast<float4*>(dst)[v] = make_float4(mh[15 - 4 * v], mh[14 - 4 * v], mh[13 - 4 * v], mh[12 - 4 * v]);
+        for (int v = 0; v < kChunk / 4; ++v)   // block cb + t sits in mh[kChunk - 1 - t]
+            reinterpret_cast<float4*>(dst)[v] = make_float4(mh[kChunk - 1 - 4 * v], mh[kChunk - 2 - 4 * v], mh[kChunk - 3 - 4 * v],
+                                                            mh[kChunk - 4 - 4 * v]);
     } else {
 #pragma unroll
         for (int t = 0; t < kChunk; ++t)
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void qprep_split_kernel(const float* __restric
     qf[npairs * 64 + idx] = lo;
 }
 
-template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1>
+template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1, int CH = kChunk, int SEC = 0>
 __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P/2][64] hi fragments, then [P/2][64] lo fragments (16 B each)
@@ -432,11 +435,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const float4* base = a.xb + b0 * P * kPieceVec4;
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();
     // lane first / second values of the current chunk (shift chains); index = query tile
-    float mh[QT][kChunk], ms[QT][kChunk];
+    // SEC: how `second` travels -- 0 = a chain like `first`, 1 = one direct 4-byte store per block to the plain
+    // [q][2 * blk + h] layout (no registers), 2 = not at all (timing experiment, wrong results)
+    float mh[QT][CH], ms[SEC == 0 ? QT : 1][SEC == 0 ? CH : 1];
 #pragma unroll
-    for (int t = 0; t < kChunk; ++t)
+    for (int t = 0; t < CH; ++t)
 #pragma unroll
-        for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; ms[u][t] = 0.f; }
+        for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; if (SEC == 0) ms[u][t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -448,9 +453,21 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
         }
     }
+    // One launch runs ceil(nq / QPP) PASSES back to back: every pass stages its own query tile and streams the wave's
+    // block range again.  The piece stream is cyclic -- the last re-arms of pass p already fetch the first pieces of pass
+    // p + 1 -- so HBM keeps streaming across the pass boundary, and there is no kernel boundary (a dependent launch
+    // costs 35-45 us of idle GPU, a third of a pass at 8-way shard sizes).
+    constexpr int QPP = 32 * QT;
+    const int npass = (a.nq + QPP - 1) / QPP;
+    const bf16x8* qhi = reinterpret_cast<const bf16x8*>(qs);
+    const bf16x8* qlo = qhi + npairs * 64;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qbase = pass * QPP;
+    const bool wrap = pass + 1 < npass;
+    if (pass) __syncthreads();  // every wave is done with the previous tile
     // Query tile: every workgroup splits the (L2-resident) row-major queries into hi/lo bf16 fragments itself -- 8 units
-    // of (pair, lane) per thread, two 16-byte reads each -- instead of a separate preparation launch: at shard sizes a
-    // kernel boundary is ~5 % of the pass.  The ring above is already streaming while this runs.
+    // of (pair, lane) per thread, two 16-byte reads each -- instead of a separate preparation launch.  The ring above
+    // is already streaming while this runs.  Waves without blocks (tiny indexes) still help staging.
     {
         u32x4* qhi_w = reinterpret_cast<u32x4*>(qs);
         u32x4* qlo_w = qhi_w + npairs * 64;
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             unsigned hA[4], lA[4], hB[4];
 #pragma unroll
             for (int tile = 0; tile < QT; ++tile) {
-            const int b = (l & 31) + 32 * tile;
+            const int b = qbase + (l & 31) + 32 * tile;
             float v[8];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -489,13 +506,8 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         }
     }
     __syncthreads();
-    if (S <= 0) {
-        if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
-        return;
-    }
+    if (S <= 0) continue;
 
-    const bf16x8* qhi = reinterpret_cast<const bf16x8*>(qs);
-    const bf16x8* qlo = qhi + npairs * 64;
     int s = 0;
     bf16x8 bh_next = qhi[lane], bl_next = qlo[lane];
     for (int64_t blk = b0; blk < b1; ++blk) {
@@ -538,8 +550,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
                     acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_lo, 0, 0, 0);
                     acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc_lo, 0, 0, 0);
                 }
-                const unsigned voff0 = lane16 + (unsigned)min(s + RING + 2 * i, S - 1) * 1024u;
-                const unsigned voff1 = lane16 + (unsigned)min(s + RING + 2 * i + 1, S - 1) * 1024u;
+                // re-arm: past the end of the range the stream wraps to the first pieces of the next pass (S >= RING
+                // whenever S > 0, so one subtraction is enough); the last pass repeats its final piece instead
+                int n0 = s + RING + 2 * i, n1 = n0 + 1;
+                n0 = n0 < S ? n0 : (wrap ? n0 - S : S - 1);
+                n1 = n1 < S ? n1 : (wrap ? n1 - S : S - 1);
+                const unsigned voff0 = lane16 + (unsigned)n0 * 1024u;
+                const unsigned voff1 = lane16 + (unsigned)n1 * 1024u;
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[2 * i]) : "v"(voff0), "s"(base) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[2 * i + 1]) : "v"(voff1), "s"(base) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -560,19 +577,23 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             } else {
                 float sec;
                 const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
-                park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, 0);
-                park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 0);
+                park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
+                if (SEC == 0) park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
+                if (SEC == 1) a.gmax2[(int64_t)(qbase + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
             }
         } else {
             float sec;
             float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h, a, sec);
-            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, 0);
-            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 0);
+            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
+            if (SEC == 0) park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
+            if (SEC == 1) a.gmax2[(int64_t)(qbase + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
             fst = block_lane_top2<METRIC>(acc_lo, nrm, blk, h, a, sec);
-            park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane, a.gmax, a.gstride, 32);
-            park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, 32);
+            park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase + 32);
+            if (SEC == 0) park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase + 32);
+            if (SEC == 1) a.gmax2[(int64_t)(qbase + 32 + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
         }
     }
+    }  // pass
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64();
 }
@@ -647,6 +668,7 @@ struct FinishArgs {
     const float* gmax2;              // the scan's second-value array, gstride floats per query
     int64_t gstride;
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
+    int chunk, sec_direct;     // blocks per flush of the scan that filled gmax; gmax2 in the plain [q][2 * blk + h] layout
     int split;                 // scan operand mode: 0 exact fp32, 1 bf16 hi/lo split, 2 split x + hi-only queries (64/pass)
 };
 
@@ -744,7 +766,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
             if (gk != 0) {
                 int64_t blk;
                 int gh;
-                group_decode(gi, a.bpw, a.nblocks, blk, gh);
+                group_decode(gi, a.bpw, a.nblocks, a.chunk, blk, gh);
                 const int r0 = 8 * g + 4 * gh;
                 const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
                 row = blk * kRowsPerBlock + r0 + (lane & 3);
@@ -866,12 +888,12 @@ __global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
         const int g = (int)(__float_as_uint(packed_value(e)) & 3u);
         int64_t blk;
         int gh;
-        group_decode(slot, a.bpw, a.nblocks, blk, gh);
+        group_decode(slot, a.bpw, a.nblocks, a.chunk, blk, gh);
         const int r0 = 8 * g + 4 * gh;
         const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
         row = blk * kRowsPerBlock + r0 + (lane & 3);
         if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
-        sec = a.gmax2[(int64_t)q * a.gstride + slot];
+        sec = a.gmax2[(int64_t)q * a.gstride + (a.sec_direct ? 2 * blk + gh : slot)];
     }
     if (lane < 4) {
         const int64_t o = (int64_t)q * kCandPerQuery + j * 4 + lane;
@@ -932,7 +954,7 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
         const int tagged = (int)(__float_as_uint(packed_value(e)) & 3u);
         int64_t blk;
         int gh;
-        group_decode((i64)packed_index(e), a.bpw, a.nblocks, blk, gh);
+        group_decode((i64)packed_index(e), a.bpw, a.nblocks, a.chunk, blk, gh);
         for (int g = 0; g < 4; ++g) {
             if (g == tagged) continue;
             const int r0 = 8 * g + 4 * gh;
@@ -1083,21 +1105,22 @@ struct DenseIndex {
     int scan_variant = 0;     // HIPRAG_SCAN_VARIANT: timing experiments only
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0; };
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0, chunk = kChunk, sec_direct = 0; int k = 0; int64_t blocks = 0; };
     static constexpr int kSlots = 8;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
-    int ws_k = 0;
-    int64_t ws_blocks = 0;
+    int launch_q = kMaxQ;     // HIPRAG_LAUNCH_QUERIES: queries one begin/finish pair takes (a multiple of the pass size)
     // stats
-    int64_t passes = 0, queries = 0;
+    int64_t passes = 0, queries = 0, launches = 0;
     // timing: a ring of event pairs around the scan kernel, averaged by get_stats (no sync inside the search path)
     static constexpr int kEvRing = 512;
     bool timing = false;
     std::vector<hipEvent_t> evs;   // 2*kEvRing once timing was enabled
     DevBuf stamps;                 // [kEvRing][n_cu * 8 waves][2] in-kernel wall-clock ticks of the same launches
     int wall_khz = 100000;
-    int64_t ev_count = 0;          // pairs recorded since timing was (re)enabled
+    int64_t ev_count = 0;          // launches since timing was (re)enabled
+    int ev_every = 1;
+    std::vector<char> ev_set;      // [kEvRing] whether the launch in that ring slot was bracketed by events
 
     int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
     unsigned* max_norm2_bits() { return scalars.as<unsigned>(); }
@@ -1118,6 +1141,10 @@ struct DenseIndex {
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
         const char* vs = getenv("HIPRAG_SCAN_VARIANT");
         scan_variant = vs ? atoi(vs) : 0;
+        const char* lq = getenv("HIPRAG_LAUNCH_QUERIES");
+        launch_q = lq ? atoi(lq) : kMaxQ;
+        launch_q = std::max(pass_queries(), std::min(kMaxQ, launch_q / pass_queries() * pass_queries()));
+        if (scan_mode == 0) launch_q = pass_queries();   // the exact-fp32 scan (verification mode) runs one pass per launch
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
@@ -1190,32 +1217,33 @@ struct DenseIndex {
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
     int kprime(int k) const { return scan_mode == 2 ? std::max(k + 22, 32) : k + kSlackGroups; }
 
-    int32_t reserve_search(int k)
+    // Workspace of one slot for (up to launch_q queries, k), allocated on first use: an unused slot costs nothing.
+    int32_t reserve_slot(int slot, int k)
     {
+        Workspace& w = ws[slot];
         const int64_t nb = std::max<int64_t>(nblocks(), 1);
-        if (k <= ws_k && nb <= ws_blocks) return HIPRAG_OK;
-        const int kk = std::max(k, ws_k);
-        const int64_t nbb = std::max(nb, ws_blocks);
+        if (k <= w.k && nb <= w.blocks) return HIPRAG_OK;
+        const int kk = std::max(k, w.k);
+        const int64_t nbb = std::max(nb, w.blocks);
         const int64_t gstride = ((2 * nbb + 3) / 4) * 4;
         const int64_t nchunks = (gstride + kSelChunk - 1) / kSelChunk;
         const int K1 = kprime(kk) + 1;
         const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
         const int ekk = std::min(kk, kExRows);
         const int64_t nlists = std::max(nchunks, ((gstride + kSelPerWave - 1) / kSelPerWave + 3) / 4 * 4);
-        for (Workspace& w : ws) {
-            int32_t rc;
-            if ((rc = w.gmax.reserve((size_t)2 * kMaxQ * gstride * sizeof(float)))) return rc;  // first | second
-            if ((rc = w.qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
-            if ((rc = w.ck.reserve((size_t)kMaxQ * nlists * K1 * sizeof(u64)))) return rc;
-            if ((rc = w.ci.reserve((size_t)kMaxQ * nlists * K1 * sizeof(i64)))) return rc;
-            if ((rc = w.flags.reserve(2 * kMaxQ * sizeof(int)))) return rc;  // flags[kMaxQ] + arrivals[kMaxQ]
-            // sel[kMaxQ][64] u64 | cand_k[kMaxQ][256] u64 | cand_i[kMaxQ][256] i64 | qn2[kMaxQ] f64 | sec[kMaxQ][64] f32
-            if ((rc = w.fin.reserve((size_t)kMaxQ * (64 + 2 * kCandPerQuery + 1 + 32) * 8))) return rc;
-            if ((rc = w.ek.reserve((size_t)kMaxQ * nslices * ekk * sizeof(u64)))) return rc;
-            if ((rc = w.ei.reserve((size_t)kMaxQ * nslices * ekk * sizeof(i64)))) return rc;
-        }
-        ws_k = kk;
-        ws_blocks = nbb;
+        const size_t Q = (size_t)launch_q;
+        int32_t rc;
+        if ((rc = w.gmax.reserve(2 * Q * gstride * sizeof(float)))) return rc;  // first | second
+        if ((rc = w.qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
+        if ((rc = w.ck.reserve(Q * nlists * K1 * sizeof(u64)))) return rc;
+        if ((rc = w.ci.reserve(Q * nlists * K1 * sizeof(i64)))) return rc;
+        if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
+        // sel[Q][64] u64 | cand_k[Q][256] u64 | cand_i[Q][256] i64 | qn2[Q] f64 | sec[Q][64] f32
+        if ((rc = w.fin.reserve(Q * (64 + 2 * kCandPerQuery + 1 + 32) * 8))) return rc;
+        if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
+        if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
+        w.k = kk;
+        w.blocks = nbb;
         return HIPRAG_OK;
     }
 
@@ -1227,20 +1255,29 @@ struct DenseIndex {
         const int64_t nb = nblocks();
         ScanArgs sa;
         sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
-        sa.gmax2 = sa.gmax + (size_t)kMaxQ * (((2 * ws_blocks + 3) / 4) * 4);
-        sa.gstride = ((2 * ws_blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
+        sa.gmax2 = sa.gmax + (size_t)launch_q * (((2 * w.blocks + 3) / 4) * 4);
+        sa.gstride = ((2 * w.blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = scan_mode != 0;
         w.split = scan_mode;
+        w.chunk = kChunk; w.sec_direct = 0;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
+        // HIP events cost two barrier packets per launch on the scan's stream; HIPRAG_TIME_EVERY=n brackets every n-th
+        // launch only (the in-kernel stamps cover every launch either way)
+        const bool use_ev = timing && ev_count % ev_every == 0;
         sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * 8 * 2 : nullptr;
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
-            if (scan_mode == 2) scan = scan_split_kernel<METRIC, 8, 16, 0, 2>;          // 64 queries, hi-only query tiles
-            else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
+            if (scan_mode == 2) {                                                        // 64 queries, hi-only query tiles
+                scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, 0>; w.chunk = 8;
+                if (scan_variant == 21) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 2>; w.chunk = 16; }
+                if (scan_variant == 22) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, 1>; w.chunk = 8; w.sec_direct = 1; }
+                if (scan_variant == 23) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 1>; w.chunk = 16; w.sec_direct = 1; }
+                if (scan_variant == 24) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 0>; w.chunk = 16; }
+            } else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
-            if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
+            if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(8 * 64), scan_lds, st, sa);
         } else {
             const int variant = scan_variant;  // timing experiments only (variants 1 and 6 give wrong scores)
@@ -1251,12 +1288,14 @@ struct DenseIndex {
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
                                w.qf.as<float4>());
-            if (timing) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
+            if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
         }
-        if (timing) { HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st)); ++ev_count; }
+        if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st));
+        if (timing) { ev_set[ev] = use_ev; ++ev_count; }
         HR_CHECK_HIP(hipGetLastError());
-        ++passes;
+        passes += (nq + pass_queries() - 1) / pass_queries();
+        ++launches;
         queries += nq;
         return HIPRAG_OK;
     }
@@ -1267,18 +1306,18 @@ struct DenseIndex {
     {
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
-        const int64_t gstride = ((2 * ws_blocks + 3) / 4) * 4;
+        const int64_t gstride = ((2 * w.blocks + 3) / 4) * 4;
         const int64_t ngroups = nb * 2;
         const int Kp = kprime(k), K1 = Kp + 1;
         const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
         int* flags = w.flags.as<int>();
-        int* arrivals = flags + kMaxQ;
+        int* arrivals = flags + launch_q;
 
         FinishArgs fa;
         fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = w.ck.as<u64>(); fa.ci = w.ci.as<i64>();
         fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
         fa.flags = flags; fa.arrivals = arrivals; fa.fallback_counter = fallback_counter();
-        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp; fa.split = w.split;
+        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp; fa.split = w.split; fa.chunk = w.chunk; fa.sec_direct = w.sec_direct;
         fa.nblocks = nb; fa.bpw = scan_blocks_per_wave(nb, (int64_t)n_cu * 8);
         const int64_t sel_waves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
         const int64_t sel_slices = (sel_waves + 3) / 4;
@@ -1290,11 +1329,11 @@ struct DenseIndex {
             fa.ncand = wave_cand;
             u64* fin_base = w.fin.as<u64>();
             fa.sel = fin_base;
-            fa.cand_k = fin_base + (size_t)kMaxQ * 64;
-            fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)kMaxQ * kCandPerQuery);
-            fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)kMaxQ * kCandPerQuery);
-            fa.sec = reinterpret_cast<float*>(fa.qn2 + kMaxQ);
-            fa.gmax2 = w.gmax.as<float>() + (size_t)kMaxQ * gstride;
+            fa.cand_k = fin_base + (size_t)launch_q * 64;
+            fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)launch_q * kCandPerQuery);
+            fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)launch_q * kCandPerQuery);
+            fa.sec = reinterpret_cast<float*>(fa.qn2 + launch_q);
+            fa.gmax2 = w.gmax.as<float>() + (size_t)launch_q * gstride;
             fa.gstride = gstride;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
@@ -1305,7 +1344,7 @@ struct DenseIndex {
             hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3((Kp + 3) / 4, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
             hipLaunchKernelGGL(fin_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, fa);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
-            hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(64), 0, st, flags, arrivals, fallback_counter(), nq);
+            hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(kMaxQ), 0, st, flags, arrivals, fallback_counter(), nq);
         } else {
             hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
                                (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
@@ -1332,12 +1371,15 @@ struct DenseIndex {
         return HIPRAG_OK;
     }
 
-    int32_t prepare(int k)
+    int32_t prepare(int k, int slot)
     {
-        int32_t rc = reserve_search(k);
+        int32_t rc = reserve_slot(slot, k);
         if (rc) return rc;
         if (timing && evs.empty()) {
             evs.resize(2 * kEvRing);
+            ev_set.assign(kEvRing, 0);
+            const char* te = getenv("HIPRAG_TIME_EVERY");
+            ev_every = te ? std::max(1, atoi(te)) : 1;
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
             int32_t src = stamps.reserve((size_t)kEvRing * n_cu * 8 * 2 * sizeof(unsigned long long));
             if (src) return src;
@@ -1361,10 +1403,10 @@ struct DenseIndex {
 
     int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
     {
-        int32_t rc = prepare(k);
+        int32_t rc = prepare(k, 0);
         if (rc) return rc;
-        for (int o = 0; o < nq; o += pass_queries()) {
-            const int m = std::min(pass_queries(), nq - o);
+        for (int o = 0; o < nq; o += launch_q) {
+            const int m = std::min(launch_q, nq - o);
             const float* qo = q_dev + (int64_t)o * d;
             if ((rc = begin_dev(qo, m, 0, st))) return rc;
             if ((rc = finish_dev(qo, m, k, 0, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
@@ -1482,11 +1524,19 @@ int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n)
     return HIPRAG_OK;
 }
 
+int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_n, "null out");
+    *out_n = ix->launch_q;
+    return HIPRAG_OK;
+}
+
 int32_t hipidx_reserve_search(uint64_t h, int32_t k)
 {
     GET_INDEX(h);
     HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
-    return ix->reserve_search(k);
+    return ix->reserve_slot(0, k);
 }
 
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
@@ -1503,11 +1553,11 @@ int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k,
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream)
 {
     GET_INDEX(h);
-    HR_REQUIRE(nq > 0 && nq <= ix->pass_queries(), "search_begin takes 1..%d queries (got %d)", ix->pass_queries(), nq);
+    HR_REQUIRE(nq > 0 && nq <= ix->launch_q, "search_begin takes 1..%d queries (got %d)", ix->launch_q, nq);
     HR_REQUIRE(k > 0 && k <= kMaxK, "k must be in 1..%d (got %d)", kMaxK, k);
     HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     HR_REQUIRE(q_dev, "null device pointer");
-    int32_t rc = ix->prepare(k);
+    int32_t rc = ix->prepare(k, slot);
     if (rc) return rc;
     return ix->begin_dev(q_dev, nq, slot, (hipStream_t)stream);
 }
@@ -1516,9 +1566,9 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
 {
     GET_INDEX(h);
-    HR_REQUIRE(nq > 0 && nq <= ix->pass_queries(), "search_finish takes 1..%d queries (got %d)", ix->pass_queries(), nq);
-    HR_REQUIRE(k > 0 && k <= ix->ws_k, "k=%d was not prepared by search_begin", k);
+    HR_REQUIRE(nq > 0 && nq <= ix->launch_q, "search_finish takes 1..%d queries (got %d)", ix->launch_q, nq);
     HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
+    HR_REQUIRE(k > 0 && k <= ix->ws[slot].k, "k=%d was not prepared by search_begin on slot %d", k, slot);
     HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
     return ix->finish_dev(q_dev, nq, k, slot, out_scores64_dev, out_scores_dev, out_ids_dev, (hipStream_t)stream);
 }
@@ -1647,6 +1697,7 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
     unsigned long long fb = 0;
     HR_CHECK_HIP(hipMemcpy(&fb, ix->fallback_counter(), sizeof(fb), hipMemcpyDeviceToHost));
     out->passes = ix->passes;
+    out->launches = ix->launches;
     out->queries = ix->queries;
     out->fallback_queries = (int64_t)fb;
     out->bytes_per_pass = ix->nblocks() * ix->P * 1024 +
@@ -1661,7 +1712,7 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
         int64_t ok = 0;
         for (int64_t i = 0; i < n; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ix->evs[2 * i], ix->evs[2 * i + 1]) == hipSuccess) { sum += ms; ++ok; }
+            if (ix->ev_set[(size_t)i] && hipEventElapsedTime(&ms, ix->evs[2 * i], ix->evs[2 * i + 1]) == hipSuccess) { sum += ms; ++ok; }
         }
         if (ok) { out->avg_scan_ms = (float)(sum / ok); out->timed_passes = ok; }
         // the same launches on the GPU's own wall clock: first wave in -> last wave out, and the idle time between the
@@ -1692,14 +1743,6 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             }
             out->avg_scan_wall_ms = (float)(dsum / n / ix->wall_khz);
             out->avg_scan_gap_ms = ordered && n > 1 ? (float)(gsum / (n - 1) / ix->wall_khz) : 0.f;
-        }
-        if (getenv("HIPRAG_DEBUG_GAPS") && ix->ev_count <= DenseIndex::kEvRing) {
-            double gsum = 0.0; int64_t gn = 0;
-            for (int64_t i = 0; i + 1 < n; ++i) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ix->evs[2 * i + 1], ix->evs[2 * i + 2]) == hipSuccess) { gsum += ms; ++gn; }
-            }
-            if (gn) fprintf(stderr, "[hiprag] mean gap between scan launches: %.2f us over %lld gaps\n", gsum / gn * 1e3, (long long)gn);
         }
     }
     return HIPRAG_OK;

@@ -26,7 +26,7 @@ class HipRagError(RuntimeError):
 class HipIdxStats(ctypes.Structure):
     _fields_ = [("passes", c_int64), ("queries", c_int64), ("fallback_queries", c_int64),
                 ("bytes_per_pass", c_int64), ("timed_passes", c_int64), ("avg_scan_ms", c_float),
-                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float)]
+                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float), ("launches", c_int64)]
 
 
 class HipBm25Stats(ctypes.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "hipidx_search_begin_dev": [c_uint64, c_void_p, c_int32, c_int32, c_int32, c_void_p],
     "hipidx_search_finish_dev": [c_uint64, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     "hipidx_pass_queries": [c_uint64, i32p],
+    "hipidx_launch_queries": [c_uint64, i32p],
     "hipidx_reserve_search": [c_uint64, c_int32],
     "hipidx_reconstruct": [c_uint64, c_int64, c_void_p],
     "hipidx_save": [c_uint64, c_char_p],

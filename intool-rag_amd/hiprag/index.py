@@ -120,9 +120,16 @@ class HipFlatIndex:
 
     @property
     def pass_queries(self) -> int:
-        """Queries one scan pass serves (search_begin's limit): 64 by default, 32 in the split / f32 operand modes."""
+        """Queries that share one read of the index: 64 by default, 32 in the split / f32 operand modes."""
         n = ctypes.c_int32()
         nat.call("hipidx_pass_queries", self._h, ctypes.byref(n))
+        return n.value
+
+    @property
+    def launch_queries(self) -> int:
+        """Queries one search_begin / search_finish pair takes: the scan runs launch/pass passes inside one launch."""
+        n = ctypes.c_int32()
+        nat.call("hipidx_launch_queries", self._h, ctypes.byref(n))
         return n.value
 
     def reserve_search(self, k: int) -> None:

@@ -51,7 +51,7 @@ class ShardedFlatIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         local.set_id_base(row_lo)
-        self.max_pass = local.pass_queries      # queries per scan pass (32 or 64, see hipidx_pass_queries)
+        self.max_pass = local.launch_queries    # queries per search_begin (see hipidx_launch_queries)
         # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
         # the tail of batch i+1, which cannot start before scan i+1 ends
         self.side = [torch.cuda.Stream(device=local.device) for _ in range(N_SLOTS)]
@@ -90,14 +90,18 @@ class ShardedFlatIndex:
         slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
         c = self._buffers(slot, nq, k, q.device)
-        # The whole pass -- scan, selection, re-score, exchange -- runs on the slot's own stream: consecutive passes sit
-        # in different hardware queues with no dependency between them, so the next scan's workgroups take over the
-        # CUs as the previous scan's drain (a scan chained behind its predecessor on one stream pays a dependent-dispatch
-        # bubble of tens of microseconds per pass).  Stream order on `side` also covers slot reuse.
+        # Scans are chained on the caller's stream (one after the other, so a scan never shares the CUs with another
+        # scan and HIP events around a launch measure that launch); everything after the scan runs on the slot's own
+        # stream beside the next scans.  A scan launch runs several passes back to back, which amortises the ~40 us
+        # dependent-dispatch bubble between chained launches.  HIPRAG_SCAN_STREAMS=side moves the scans to the slot
+        # streams too (scan i released when scan i-2 completes): ~1 % (1M rows) to 3 % (125k-row shard) more throughput,
+        # but consecutive scans then overlap at their ragged ends and per-launch event times include queueing.
         side = self.side[slot]
         pack = c["pack"]
-        if os.environ.get("HIPRAG_SCAN_ON_MAIN") == "1":
+        if os.environ.get("HIPRAG_SCAN_STREAMS") != "side":
             if self._slot_used[slot] and not self._slot_ended[slot]:
+                # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
+                # waited there and stream order covers it (one barrier packet less per step)
                 main.wait_event(c["fin"] if self.world > 1 else c["done"])
             self.local.search_begin(q, k, slot, stream=main.cuda_stream)
             c["scanned"].record(main)
@@ -105,11 +109,8 @@ class ShardedFlatIndex:
         else:
             c["scanned"].record(main)          # q was produced on the caller's stream
             side.wait_event(c["scanned"])
-            # at most ONE scan waits behind the running one: two scans released together would share the CUs and both
-            # finish late.  Scan i is released when scan i-2 completes, i.e. while scan i-1 runs, so the wait is hidden.
-            lag = int(os.environ.get("HIPRAG_SCAN_LAG", "2"))
-            before = (slot - lag) % N_SLOTS
-            if lag > 0 and self._slot_used[before]:
+            before = (slot - 2) % N_SLOTS
+            if self._slot_used[before]:
                 side.wait_event(self._scan_done[before])
             self.local.search_begin(q, k, slot, stream=self._side_ptr[slot])
             self._scan_done[slot].record(side)

@@ -235,3 +235,20 @@ def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mo
     _check(ix, x, q, k, metric)
     _check(ix, x, q[:1], 50, metric)
     assert ix.stats()["fallback_queries"] >= 1          # the zero query (and maybe the duplicate one) took the exhaustive path
+
+
+@pytest.mark.parametrize("mode", ["split", "q64"])
+@pytest.mark.parametrize("nq", [65, 129, 256, 300])
+def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
+    """One scan launch runs several passes back to back (cyclic piece stream, query tile re-staged per pass): ragged
+    last passes, launches of exactly launch_queries and more than one launch, on an index small enough that some waves
+    of the grid have no blocks at all, and on one where every wave has several."""
+    from hiprag import HipFlatIndex
+    monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
+    for n, d in ((900, 96), (70001, 256)):
+        x = ho.synthetic_vectors(n, d, seed=91)
+        q = ho.synthetic_queries(nq, d, seed=92)
+        ix = HipFlatIndex(d, ho.METRIC_IP)
+        assert ix.launch_queries == 256
+        ix.add(x)
+        _check(ix, x, q, 10, ho.METRIC_IP)
