@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void qprep_split_kernel(const float* __restric
     qf[npairs * 64 + idx] = lo;
 }
 
-template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1, int CH = kChunk, int SEC = 0>
+template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1, int CH = kChunk, bool MULTI = true>
 __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P/2][64] hi fragments, then [P/2][64] lo fragments (16 B each)
@@ -435,13 +435,11 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const float4* base = a.xb + b0 * P * kPieceVec4;
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();
     // lane first / second values of the current chunk (shift chains); index = query tile
-    // SEC: how `second` travels -- 0 = a chain like `first`, 1 = one direct 4-byte store per block to the plain
-    // [q][2 * blk + h] layout (no registers), 2 = not at all (timing experiment, wrong results)
-    float mh[QT][CH], ms[SEC == 0 ? QT : 1][SEC == 0 ? CH : 1];
+    float mh[QT][CH], ms[QT][CH];
 #pragma unroll
     for (int t = 0; t < CH; ++t)
 #pragma unroll
-        for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; if (SEC == 0) ms[u][t] = 0.f; }
+        for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; ms[u][t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
 
@@ -458,7 +456,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     // p + 1 -- so HBM keeps streaming across the pass boundary, and there is no kernel boundary (a dependent launch
     // costs 35-45 us of idle GPU, a third of a pass at 8-way shard sizes).
     constexpr int QPP = 32 * QT;
-    const int npass = (a.nq + QPP - 1) / QPP;
+    // MULTI = false is the single-pass form (nq <= QPP) that latency-bound callers -- one query at a time -- get: no
+    // pass loop, and its own kernel name in profiles
+    const int npass = MULTI ? (a.nq + QPP - 1) / QPP : 1;
     const bf16x8* qhi = reinterpret_cast<const bf16x8*>(qs);
     const bf16x8* qlo = qhi + npairs * 64;
     for (int pass = 0; pass < npass; ++pass) {
@@ -578,19 +578,16 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
                 float sec;
                 const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
                 park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-                if (SEC == 0) park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
-                if (SEC == 1) a.gmax2[(int64_t)(qbase + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
+                park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
             }
         } else {
             float sec;
             float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h, a, sec);
             park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-            if (SEC == 0) park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
-            if (SEC == 1) a.gmax2[(int64_t)(qbase + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
+            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
             fst = block_lane_top2<METRIC>(acc_lo, nrm, blk, h, a, sec);
             park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase + 32);
-            if (SEC == 0) park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase + 32);
-            if (SEC == 1) a.gmax2[(int64_t)(qbase + 32 + (lane & 31)) * a.gstride + 2 * blk + h] = sec;
+            park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase + 32);
         }
     }
     }  // pass
@@ -668,7 +665,8 @@ struct FinishArgs {
     const float* gmax2;              // the scan's second-value array, gstride floats per query
     int64_t gstride;
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
-    int chunk, sec_direct;     // blocks per flush of the scan that filled gmax; gmax2 in the plain [q][2 * blk + h] layout
+    unsigned long long* dbg;   // HIPRAG_DEBUG_GAPS only: [8] wall-clock stamps of this launch's tail kernels
+    int chunk;                 // blocks per flush of the scan that filled gmax
     int split;                 // scan operand mode: 0 exact fp32, 1 bf16 hi/lo split, 2 split x + hi-only queries (64/pass)
 };
 
@@ -823,6 +821,7 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;
     const int K1 = a.Kp + 1;
+    if (a.dbg && tid == 0) atomicMin(a.dbg + 1, (unsigned long long)wall_clock64());
 
     double qpart = 0.0;
     for (int c = tid; c < a.d; c += NT) {
@@ -876,6 +875,7 @@ __global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int j = blockIdx.x * 4 + (tid >> 6), q = blockIdx.y;
     const int dpad = a.P * 8;
+    if (a.dbg && tid == 0) atomicMin(a.dbg + 2, (unsigned long long)wall_clock64());
     for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
     __syncthreads();
     if (j >= a.Kp) return;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void fin_rescore_kernel(FinishArgs a)
         const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
         row = blk * kRowsPerBlock + r0 + (lane & 3);
         if (row < a.ntotal) key = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
-        sec = a.gmax2[(int64_t)q * a.gstride + (a.sec_direct ? 2 * blk + gh : slot)];
+        sec = a.gmax2[(int64_t)q * a.gstride + slot];
     }
     if (lane < 4) {
         const int64_t o = (int64_t)q * kCandPerQuery + j * 4 + lane;
@@ -912,6 +912,7 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
     __shared__ float qv[kMaxDPad];  // staged only when a group needs its other quads
     const int q = blockIdx.x, lane = threadIdx.x;
     const int ncand = a.Kp * 4;
+    if (a.dbg && lane == 0) atomicMin(a.dbg + 3, (unsigned long long)wall_clock64());
     const u64* ck = a.cand_k + (int64_t)q * kCandPerQuery;
     const i64* ci = a.cand_i + (int64_t)q * kCandPerQuery;
     u64 ckc[4];
@@ -977,6 +978,7 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
         a.flags[q] = flag;
         a.arrivals[q] = 0;
         if (flag) atomicAdd(a.fallback_counter, 1ull);
+        if (a.dbg) atomicMin(a.dbg + 4, ~(unsigned long long)wall_clock64());
     }
 }
 
@@ -1007,6 +1009,7 @@ struct ExArgs {
     int64_t* out_ids;
     int64_t ntotal, id_base;
     int d, P, k, kk, nslices, nq;
+    unsigned long long* dbg;
 };
 
 // One launch: workgroup s re-scores rows [s*kExRows, +kExRows) of every FLAGGED query in fp64 and publishes its best
@@ -1025,9 +1028,13 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_kernel(ExArgs a)
     int* ticket = reinterpret_cast<int*>(qv + a.P * 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dpad = a.P * 8;
-    bool any = false;
-    for (int q = 0; q < a.nq; ++q) any = any || a.flags[q] != 0;
-    if (!any) return;  // the common case: a <= n_cu-workgroup launch that reads nq flags and leaves
+    if (a.dbg && tid == 0) atomicMin(a.dbg + 5, (unsigned long long)wall_clock64());
+    int mine = 0;
+    for (int q = tid; q < a.nq; q += kSelThreads) mine |= a.flags[q];
+    if (!__syncthreads_or(mine)) {  // the common case: a <= n_cu-workgroup launch that reads nq flags and leaves
+        if (a.dbg && tid == 0) atomicMin(a.dbg + 6, ~(unsigned long long)wall_clock64());
+        return;
+    }
     for (int slice = blockIdx.x; slice < a.nslices; slice += gridDim.x) {
         const int64_t row_base = (int64_t)slice * kExRows;
         const int nrows = (int)min((int64_t)kExRows, a.ntotal - row_base);
@@ -1101,11 +1108,12 @@ struct DenseIndex {
     int d = 0, P = 0, metric = 0;
     int64_t ntotal = 0, cap_blocks = 0, id_base = 0;
     int n_cu = 256;
+    int scan_cus = 256;       // workgroups of a scan launch (one per CU); HIPRAG_SCAN_SPARE_CUS leaves some CUs to the tails
     int scan_mode = 2;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo, 32 q/pass), q64 = 2 (default)
     int scan_variant = 0;     // HIPRAG_SCAN_VARIANT: timing experiments only
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0, chunk = kChunk, sec_direct = 0; int k = 0; int64_t blocks = 0; };
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0, chunk = kChunk; int k = 0; int64_t blocks = 0; int ev_idx = -1; };
     static constexpr int kSlots = 8;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
@@ -1116,6 +1124,8 @@ struct DenseIndex {
     static constexpr int kEvRing = 512;
     bool timing = false;
     std::vector<hipEvent_t> evs;   // 2*kEvRing once timing was enabled
+    DevBuf dbg_stamps;             // HIPRAG_DEBUG_GAPS: [kEvRing][8] tail-kernel stamps
+    bool dbg_on = false;
     DevBuf stamps;                 // [kEvRing][n_cu * 8 waves][2] in-kernel wall-clock ticks of the same launches
     int wall_khz = 100000;
     int64_t ev_count = 0;          // launches since timing was (re)enabled
@@ -1137,6 +1147,8 @@ struct DenseIndex {
         hipDeviceProp_t prop;
         HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const char* sp = getenv("HIPRAG_SCAN_SPARE_CUS");
+        scan_cus = std::max(1, n_cu - (sp ? atoi(sp) : (n_cu >= 64 ? 8 : 0)));
         const char* ms = getenv("HIPRAG_SCAN_MODE");
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
         const char* vs = getenv("HIPRAG_SCAN_VARIANT");
@@ -1260,25 +1272,24 @@ struct DenseIndex {
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = scan_mode != 0;
         w.split = scan_mode;
-        w.chunk = kChunk; w.sec_direct = 0;
+        w.chunk = kChunk;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
         // HIP events cost two barrier packets per launch on the scan's stream; HIPRAG_TIME_EVERY=n brackets every n-th
         // launch only (the in-kernel stamps cover every launch either way)
         const bool use_ev = timing && ev_count % ev_every == 0;
-        sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * 8 * 2 : nullptr;
+        sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * 8 * 2 : nullptr;
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
+            const bool one_pass = nq <= pass_queries();
+            if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 1, kChunk, false>;
             if (scan_mode == 2) {                                                        // 64 queries, hi-only query tiles
-                scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, 0>; w.chunk = 8;
-                if (scan_variant == 21) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 2>; w.chunk = 16; }
-                if (scan_variant == 22) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, 1>; w.chunk = 8; w.sec_direct = 1; }
-                if (scan_variant == 23) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 1>; w.chunk = 16; w.sec_direct = 1; }
-                if (scan_variant == 24) { scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 16, 0>; w.chunk = 16; }
+                scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8>; w.chunk = 8;
+                if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, false>;
             } else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
-            if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(8 * 64), scan_lds, st, sa);
+            if (nb > 0) hipLaunchKernelGGL(scan, dim3(scan_cus), dim3(8 * 64), scan_lds, st, sa);
         } else {
             const int variant = scan_variant;  // timing experiments only (variants 1 and 6 give wrong scores)
             int NW = 8;
@@ -1289,9 +1300,10 @@ struct DenseIndex {
             hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
                                w.qf.as<float4>());
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
-            if (nb > 0) hipLaunchKernelGGL(scan, dim3(n_cu), dim3(NW * 64), scan_lds, st, sa);
+            if (nb > 0) hipLaunchKernelGGL(scan, dim3(scan_cus), dim3(NW * 64), scan_lds, st, sa);
         }
         if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st));
+        w.ev_idx = timing ? ev : -1;
         if (timing) { ev_set[ev] = use_ev; ++ev_count; }
         HR_CHECK_HIP(hipGetLastError());
         passes += (nq + pass_queries() - 1) / pass_queries();
@@ -1317,15 +1329,17 @@ struct DenseIndex {
         fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = w.ck.as<u64>(); fa.ci = w.ci.as<i64>();
         fa.max_norm2_bits = max_norm2_bits(); fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp;
         fa.flags = flags; fa.arrivals = arrivals; fa.fallback_counter = fallback_counter();
-        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp; fa.split = w.split; fa.chunk = w.chunk; fa.sec_direct = w.sec_direct;
-        fa.nblocks = nb; fa.bpw = scan_blocks_per_wave(nb, (int64_t)n_cu * 8);
+        fa.dbg = (dbg_on && w.ev_idx >= 0) ? dbg_stamps.as<unsigned long long>() + (size_t)w.ev_idx * 8 : nullptr;
+        if (fa.dbg) HR_CHECK_HIP(hipMemsetAsync(fa.dbg, 0xFF, 64, st));
+        fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.Kp = Kp; fa.split = w.split; fa.chunk = w.chunk;
+        fa.nblocks = nb; fa.bpw = scan_blocks_per_wave(nb, (int64_t)scan_cus * 8);
         const int64_t sel_waves = std::max<int64_t>(1, (ngroups + kSelPerWave - 1) / kSelPerWave);
         const int64_t sel_slices = (sel_waves + 3) / 4;
         const int64_t wave_cand = sel_slices * 4 * K1;
         if (K1 <= 64 && wave_cand <= (int64_t)kFinWaves * 64 * 16) {
             // fast selectors: one wave filters kSelPerWave group maxima against its running K1-th best
             hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)sel_slices, nq), dim3(256), 0, st,
-                               (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
+                               (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>(), fa.dbg);
             fa.ncand = wave_cand;
             u64* fin_base = w.fin.as<u64>();
             fa.sel = fin_base;
@@ -1362,6 +1376,7 @@ struct DenseIndex {
         ea.out64 = o64p; ea.out32 = o32p; ea.out_ids = oidp; ea.ntotal = ntotal; ea.id_base = id_base;
         ea.d = d; ea.P = P; ea.k = k; ea.kk = std::min(k, kExRows); ea.nq = nq;
         ea.nslices = (int)std::max<int64_t>(1, (ntotal + kExRows - 1) / kExRows);
+        ea.dbg = fa.dbg;
         const size_t ex_lds = (size_t)kExRows * 16 + (size_t)k * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
                               (size_t)P * 8 * sizeof(float) + 16;
         auto exk = exhaustive_kernel<METRIC>;
@@ -1381,8 +1396,10 @@ struct DenseIndex {
             const char* te = getenv("HIPRAG_TIME_EVERY");
             ev_every = te ? std::max(1, atoi(te)) : 1;
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
-            int32_t src = stamps.reserve((size_t)kEvRing * n_cu * 8 * 2 * sizeof(unsigned long long));
+            int32_t src = stamps.reserve((size_t)kEvRing * scan_cus * 8 * 2 * sizeof(unsigned long long));
             if (src) return src;
+            dbg_on = getenv("HIPRAG_DEBUG_GAPS") != nullptr;
+            if (dbg_on) { int32_t drc = dbg_stamps.reserve((size_t)kEvRing * 8 * 8); if (drc) return drc; }
             (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device);
             if (wall_khz <= 0) wall_khz = 100000;
         }
@@ -1718,7 +1735,7 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
         // the same launches on the GPU's own wall clock: first wave in -> last wave out, and the idle time between the
         // last wave of one scan and the first wave of the next (negative = the next scan started on CUs already free)
         if (ix->stamps.p && ix->nblocks() > 0) {
-            const size_t per = (size_t)ix->n_cu * 8 * 2;
+            const size_t per = (size_t)ix->scan_cus * 8 * 2;
             std::vector<unsigned long long> hst((size_t)n * per);
             HR_CHECK_HIP(hipMemcpy(hst.data(), ix->stamps.p, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             std::vector<std::pair<unsigned long long, unsigned long long>> se((size_t)n);
@@ -1734,12 +1751,18 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             for (int64_t i = 0; i < n; ++i) dsum += (double)(se[(size_t)i].second - se[(size_t)i].first);
             const bool ordered = ix->ev_count <= DenseIndex::kEvRing;
             for (int64_t i = 0; ordered && i + 1 < n; ++i) gsum += (double)((long long)se[(size_t)i + 1].first - (long long)se[(size_t)i].second);
-            if (getenv("HIPRAG_DEBUG_GAPS") && ordered) {
-                fprintf(stderr, "[hiprag] scan wall us / gap-to-next us:");
-                for (int64_t i = 40; i < std::min<int64_t>(n - 1, 72); ++i)
-                    fprintf(stderr, " %.0f/%.0f", (double)(se[(size_t)i].second - se[(size_t)i].first) * 1e3 / ix->wall_khz,
-                            (double)((long long)se[(size_t)i + 1].first - (long long)se[(size_t)i].second) * 1e3 / ix->wall_khz);
-                fprintf(stderr, "\n");
+            if (ix->dbg_on && ordered && ix->dbg_stamps.p) {
+                std::vector<unsigned long long> ds((size_t)n * 8);
+                HR_CHECK_HIP(hipMemcpy(ds.data(), ix->dbg_stamps.p, ds.size() * 8, hipMemcpyDeviceToHost));
+                const double tk = 1e3 / ix->wall_khz;
+                fprintf(stderr, "[hiprag] per launch, us after its scan's first wave: scan_end | select_in merge_in rescore_in final_in final_out exh_in exh_out | next scan in\n");
+                for (int64_t i = 40; i < std::min<int64_t>(n - 1, 52); ++i) {
+                    const unsigned long long t0 = se[(size_t)i].first;
+                    auto rel = [&](unsigned long long t) { return (double)((long long)t - (long long)t0) * tk; };
+                    const unsigned long long* d8 = &ds[(size_t)i * 8];
+                    fprintf(stderr, "  %7.0f | %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f | %7.0f\n", rel(se[(size_t)i].second), rel(d8[0]),
+                            rel(d8[1]), rel(d8[2]), rel(d8[3]), rel(~d8[4]), rel(d8[5]), rel(~d8[6]), rel(se[(size_t)i + 1].first));
+                }
             }
             out->avg_scan_wall_ms = (float)(dsum / n / ix->wall_khz);
             out->avg_scan_gap_ms = ordered && n > 1 ? (float)(gsum / (n - 1) / ix->wall_khz) : 0.f;

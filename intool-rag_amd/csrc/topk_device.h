@@ -306,8 +306,10 @@ __device__ __forceinline__ void wave_topk_packed(const u64 (&c)[N], int K, WaveL
 constexpr int kSelPerWave = 4096;
 template <bool POSITIVE_ONLY>
 __global__ __launch_bounds__(256) void select_wave_kernel(const float* __restrict__ vals, i64 stride, i64 n_total, int K1,
-                                                         u64* __restrict__ ck, i64* __restrict__ ci)
+                                                         u64* __restrict__ ck, i64* __restrict__ ci,
+                                                         unsigned long long* dbg_stamp = nullptr)
 {
+    if (dbg_stamp && threadIdx.x == 0) atomicMin(dbg_stamp, (unsigned long long)wall_clock64());
     constexpr int NV = kSelPerWave / 256;  // float4 loads per lane
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.y;

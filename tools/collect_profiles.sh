@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's judged artefacts on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats of the same
+# command, the sequential per-kernel profile and the two PMC passes of the scan.  Everything lands in gpurun_out/<tag>_*;
+# copy what is to be judged into profiles/.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+export TMPDIR=/tmp
+cd $R && python3 bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err || exit 1
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_seq -- python3 $R/tools/seq_search.py > $O/${TAG}_prof_seq.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/tools/seq_search.py > $O/${TAG}_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/tools/seq_search.py > $O/${TAG}_pmc_write.log 2>&1 || exit 1
+cd $R
+python3 tools/pmc_summary.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_scan.json 16384000000
+for t in prof_bench prof_seq; do
+  cp $(ls $O/${TAG}_$t/*/*_kernel_stats.csv | head -1) $O/${TAG}_${t}_kernel_stats.csv
+done
+python3 - <<PY
+import csv
+for t in ("prof_bench", "prof_seq"):
+    print("==", t)
+    for r in list(csv.DictReader(open("$O/${TAG}_%s_kernel_stats.csv" % t)))[:10]:
+        print(r["Name"][:70].ljust(70), r["Calls"].rjust(5), ("%.1f" % (float(r["AverageNs"]) / 1e3)).rjust(9), "us", r["Percentage"])
+PY
+cat $O/${TAG}_bench_n1.json
