@@ -1226,8 +1226,13 @@ struct DenseIndex {
     }
 
     int pass_queries() const { return scan_mode == 2 ? 64 : 32; }
+    // Operand mode of a launch for top-k: the 64-query tiles need K' = k + 22 re-scored groups, and the wave-list
+    // selectors hold 64 entries, so deeper k (the hybrid retriever's fusion depth 50) runs the 32-query split scan
+    // (K' = k + 6), which stays on the fast finish path up to k = 57.
+    int mode_for(int k) const { return (scan_mode == 2 && std::max(k + 22, 32) + 1 > 64) ? 1 : scan_mode; }
+    int pass_queries_for(int k) const { return mode_for(k) == 2 ? 64 : 32; }
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
-    int kprime(int k) const { return scan_mode == 2 ? std::max(k + 22, 32) : k + kSlackGroups; }
+    int kprime(int k) const { return mode_for(k) == 2 ? std::max(k + 22, 32) : k + kSlackGroups; }
 
     // Workspace of one slot for (up to launch_q queries, k), allocated on first use: an unused slot costs nothing.
     int32_t reserve_slot(int slot, int k)
@@ -1261,8 +1266,9 @@ struct DenseIndex {
 
     // phase 1 of a pass (<= kMaxQ queries): query fragments + the scan, into workspace `slot`
     template <int METRIC>
-    int32_t scan_pass(const float* q_dev, int nq, int slot, hipStream_t st)
+    int32_t scan_pass(const float* q_dev, int nq, int k, int slot, hipStream_t st)
     {
+        const int mode = mode_for(k);
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
         ScanArgs sa;
@@ -1270,8 +1276,8 @@ struct DenseIndex {
         sa.gmax2 = sa.gmax + (size_t)launch_q * (((2 * w.blocks + 3) / 4) * 4);
         sa.gstride = ((2 * w.blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
-        const bool split = scan_mode != 0;
-        w.split = scan_mode;
+        const bool split = mode != 0;
+        w.split = mode;
         w.chunk = kChunk;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
@@ -1281,9 +1287,9 @@ struct DenseIndex {
         sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * 8 * 2 : nullptr;
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
-            const bool one_pass = nq <= pass_queries();
+            const bool one_pass = nq <= pass_queries_for(k);
             if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 1, kChunk, false>;
-            if (scan_mode == 2) {                                                        // 64 queries, hi-only query tiles
+            if (mode == 2) {                                                             // 64 queries, hi-only query tiles
                 scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8>; w.chunk = 8;
                 if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, false>;
             } else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
@@ -1306,7 +1312,7 @@ struct DenseIndex {
         w.ev_idx = timing ? ev : -1;
         if (timing) { ev_set[ev] = use_ev; ++ev_count; }
         HR_CHECK_HIP(hipGetLastError());
-        passes += (nq + pass_queries() - 1) / pass_queries();
+        passes += (nq + pass_queries_for(k) - 1) / pass_queries_for(k);
         ++launches;
         queries += nq;
         return HIPRAG_OK;
@@ -1406,10 +1412,10 @@ struct DenseIndex {
         return HIPRAG_OK;
     }
 
-    int32_t begin_dev(const float* q_dev, int nq, int slot, hipStream_t st)
+    int32_t begin_dev(const float* q_dev, int nq, int k, int slot, hipStream_t st)
     {
-        return metric == HIPRAG_METRIC_IP ? scan_pass<HIPRAG_METRIC_IP>(q_dev, nq, slot, st)
-                                          : scan_pass<HIPRAG_METRIC_L2>(q_dev, nq, slot, st);
+        return metric == HIPRAG_METRIC_IP ? scan_pass<HIPRAG_METRIC_IP>(q_dev, nq, k, slot, st)
+                                          : scan_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, st);
     }
 
     int32_t finish_dev(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
@@ -1425,7 +1431,7 @@ struct DenseIndex {
         for (int o = 0; o < nq; o += launch_q) {
             const int m = std::min(launch_q, nq - o);
             const float* qo = q_dev + (int64_t)o * d;
-            if ((rc = begin_dev(qo, m, 0, st))) return rc;
+            if ((rc = begin_dev(qo, m, k, 0, st))) return rc;
             if ((rc = finish_dev(qo, m, k, 0, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
                                  oidp + (int64_t)o * k, st)))
                 return rc;
@@ -1576,7 +1582,7 @@ int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int3
     HR_REQUIRE(q_dev, "null device pointer");
     int32_t rc = ix->prepare(k, slot);
     if (rc) return rc;
-    return ix->begin_dev(q_dev, nq, slot, (hipStream_t)stream);
+    return ix->begin_dev(q_dev, nq, k, slot, (hipStream_t)stream);
 }
 
 int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,

@@ -252,3 +252,21 @@ def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
         assert ix.launch_queries == 256
         ix.add(x)
         _check(ix, x, q, 10, ho.METRIC_IP)
+
+
+def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
+    """k = 50 (the hybrid retriever's fusion depth) needs more re-scored groups than the 64-query tiles' selectors hold,
+    so those launches run the 32-query split scan; k = 10 on the same index keeps the 64-query tiles."""
+    from hiprag import HipFlatIndex
+    n, d = 30000, 384
+    x = ho.synthetic_vectors(n, d, seed=95)
+    q = ho.synthetic_queries(100, d, seed=96)
+    ix = HipFlatIndex(d, ho.METRIC_IP)
+    ix.add(x)
+    p0 = ix.stats()["passes"]
+    _check(ix, x, q, 50, ho.METRIC_IP)
+    p1 = ix.stats()["passes"]
+    _check(ix, x, q, 10, ho.METRIC_IP)
+    p2 = ix.stats()["passes"]
+    assert (p1 - p0, p2 - p1) == (4, 2)          # 100 queries: 4 passes of 32, then 2 passes of 64
+    assert ix.stats()["fallback_queries"] == 0
