@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -67,8 +70,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0

@@ -95,5 +95,19 @@ class HipEmbeddingProvider(EmbeddingProvider):
             logger.error(f"[EMBED] HIP embed_batch failed: {e}")
             raise
 
+    async def embed_batch_device(self, texts: List[str]):
+        """embed_batch without the list-of-lists round trip: a float32 CUDA tensor [n, dim] (the ingest side feeds it
+        straight into the index, rag/ingest/indexing.py).  Same text cleaning as embed_batch."""
+        import torch
+        if not texts:
+            return torch.empty((0, self._dimension), dtype=torch.float32, device=f"cuda:{self.encoder.device}")
+        clean_texts = [t.strip() if t and t.strip() else "" for t in texts]
+
+        def run():
+            toks = [self.tokenizer.encode(t.replace("\n", " "), self.encoder.cfg.max_seq_len) for t in clean_texts]
+            with self._lock:
+                return self.encoder.encode_tokens(toks, batch_size=max(32, config.EMBEDDING_BATCH_SIZE))
+        return await asyncio.to_thread(run)
+
     def dimension(self) -> int:
         return self._dimension

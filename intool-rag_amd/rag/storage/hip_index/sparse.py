@@ -22,11 +22,27 @@ def get_sparse_index(storage_path: Path, doc_id: str, chunks_list: List[Dict[str
         hit = _SPARSE_CACHE.get(key)
         if hit is not None and hit[0] == id(chunks_list):
             return hit[1]
+        if hit is not None and isinstance(hit[0], tuple):          # built at ingest time from the same texts
+            texts = [c.get("text", "") for c in chunks_list]
+            if hit[0] == ("texts", len(texts), hash(tuple(texts))):
+                _SPARSE_CACHE[key] = (id(chunks_list), hit[1])
+                return hit[1]
     postings = build_postings_from_texts([c.get("text", "") for c in chunks_list])
     index = HipBM25(postings, device=config.HIP_DEVICE)
     with _LOCK:
         _SPARSE_CACHE[key] = (id(chunks_list), index)
     return index
+
+
+def put_sparse_index(storage_path: Path, doc_id: str, texts: List[str]) -> int:
+    """Ingest side: build the postings of `texts` (row id == position) and keep the index for the readers of this
+    document; get_sparse_index rebuilds only if it is later handed a different chunk table.  Returns the postings count."""
+    from hiprag import HipBM25, build_postings_from_texts
+    postings = build_postings_from_texts(texts)
+    index = HipBM25(postings, device=config.HIP_DEVICE)
+    with _LOCK:
+        _SPARSE_CACHE[str(Path(storage_path) / doc_id)] = (("texts", len(texts), hash(tuple(texts))), index)
+    return int(postings.offsets[-1])
 
 
 def clear_sparse_cache() -> None:

@@ -247,3 +247,62 @@ def test_overlay_reads_index_files_written_by_the_reference_format(gpu, tmp_path
     got = asyncio.run(hi.search_hip_by_vector(case["query"], limit=case["limit"]))
     assert [r["chunk_id"] for r in got] == [r["chunk_id"] for r in case["expected"]]
     hi.clear_caches()
+
+
+def test_ingest_indexing_then_retrieval_config1_scale(gpu, tmp_path, monkeypatch):
+    """BASELINE configs[0] shape end to end on the GPU: 10k chunks -> index_chunks (embed_batch on the encoder, vectors
+    straight from HBM into the index, postings from the same texts; rag/ingest/ingestion_pipeline.py:80-94) ->
+    retrieve_and_rank_pages through the provider.  The retrieval legs are checked against the oracle ON THE VECTORS THE
+    GPU STORED (the encoder's own parity is test_encoder_gpu.py); dense ids bit-exact, page ranking equal."""
+    import rag.storage.hip_index as hi
+    import rag.llm.embeddings.factory as fac
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    from rag.ingest import index_chunks
+    from rag.providers.hip.embeddings import HipEmbeddingProvider
+    from rag.providers.hip.tokenizer import HashTokenizer
+    from rag.query.retriever import HybridRetriever, retrieve_and_rank_pages
+    from rag.storage.hip_index.sparse import clear_sparse_cache
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path))
+    hi.clear_caches()
+    clear_sparse_cache()
+    cfg = EncoderConfig(vocab=4000, hidden=128, layers=2, heads=2, ffn=256, max_pos=80, max_seq_len=64)
+    enc = HipEncoder(cfg, random_state(cfg, seed=21))
+    prov = HipEmbeddingProvider(encoder=enc, tokenizer=HashTokenizer(cfg.vocab))
+    rng = np.random.default_rng(8)
+    vocab = [f"w{i}" for i in range(600)]
+    n = 10000
+    texts = [" ".join(rng.choice(vocab, size=int(rng.integers(5, 14)))) + f" id{i}" for i in range(n)]
+    chunks = {"total": n, "chunks": [{"chunk_id": f"c_{1 + i // 8:04d}_{i % 8:03d}", "page": 1 + i // 8, "text": texts[i],
+                                      "chunk_index": i % 8} for i in range(n)]}
+    with open(tmp_path / "docC_chunks.json", "w") as f:
+        json.dump(chunks, f)
+    fac.set_embedding_provider(prov)
+    try:
+        summary = asyncio.run(index_chunks("docC", chunks["chunks"], storage_dir=tmp_path, with_sparse=True))
+        assert summary["success"] and summary["vectors_indexed"] == n and summary["postings_indexed"] > n
+        assert (tmp_path / f"docC{hi.INDEX_SUFFIX}").exists()
+        reader = hi.HipIndexReader(str(tmp_path / f"docC{hi.INDEX_SUFFIX}"))
+        stored = np.stack([reader.index.reconstruct(i) for i in range(n)])
+        assert np.allclose(np.linalg.norm(stored, axis=1), 1.0, atol=1e-3)
+        for qtext in (texts[1234], texts[77] + " " + texts[78], "w3 w5 w8 id4321"):
+            qvec = np.asarray(asyncio.run(prov.embed_single(qtext)), dtype=np.float32)
+            pages = asyncio.run(retrieve_and_rank_pages(qtext, top_pages=5))
+            dist, ids = ho.flat_search(stored, qvec, 50, ho.METRIC_L2)
+            res = ho.reader_search_transform(dist[0], ids[0])
+            oc = [ho.OChunk(chunks["chunks"][i]["chunk_id"], texts[i], s, chunks["chunks"][i]["page"]) for i, s in res]
+            exp = ho.rank_pages(oc, 5)
+            assert [(p.page, [c.chunk_id for c in p.chunks]) for p in pages] == [(p, cid) for p, _, cid in exp]
+            # hybrid on top of the ingest-time postings
+            got = asyncio.run(HybridRetriever(top_chunks=50, top_pages=5, hybrid=True).retrieve_chunks(qtext))
+            op = ho.build_postings_from_texts(texts)
+            qterms = [op.vocab[t] for t in ho.tokenize(qtext) if t in op.vocab]
+            _, sparse_ids = ho.bm25_search(op, [qterms], 50)
+            dense_ids = np.asarray([[i for i, _ in res]], dtype=np.int64)
+            _, fi = ho.rrf_fuse(dense_ids, sparse_ids, 50)
+            assert [c.chunk_id for c in got] == [chunks["chunks"][int(i)]["chunk_id"] for i in fi[0] if i >= 0]
+        assert any(c.chunk_id == chunks["chunks"][1234]["chunk_id"] for p in asyncio.run(
+            retrieve_and_rank_pages(texts[1234], top_pages=5)) for c in p.chunks)
+    finally:
+        fac.set_embedding_provider(None)
+        hi.clear_caches()
+        clear_sparse_cache()
