@@ -10,6 +10,7 @@
 // Layout: CSR postings in HBM as two SoA streams (doc_ids u32, impacts f32) -- 8 B per posting, read once per use,
 // coalesced 16 B per lane; accumulators acc[query][doc] fp32 stay L2 / Infinity-Cache resident (4 MB per query per
 // 1M docs).  Bound: HBM (posting streams) + the accumulator zero/select passes; bytes reported by hipbm25_get_stats.
+#include <algorithm>
 #include <cfloat>
 #include <vector>
 
@@ -39,15 +40,162 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
     const u64 start = r.lo + (u64)blockIdx.x * kTaatChunk;
     if (start >= r.hi) return;
     float* accb = acc + (i64)b * n_docs;  // n_docs here is the padded row stride
-    // strided by thread so that each load instruction is a contiguous 1 KiB (u32/f32 x 256 threads)
+    // strided by thread so that each load instruction is a contiguous 1 KiB (u32/f32 x 256 threads).  A document
+    // occurs at most once in a posting list, so the eight read-modify-writes of a thread never alias: all eight
+    // accumulator loads go out together (written as three separate loops -- left as acc[d] += x the compiler must assume
+    // aliasing and serialises eight L2 round trips per thread, which made the kernel latency-bound at ~1 TB/s).
+    u32 d[kTaatPerThread];
+    float im[kTaatPerThread], a[kTaatPerThread];
 #pragma unroll
     for (int j = 0; j < kTaatPerThread; ++j) {
         const u64 i = start + (u64)j * kTaatThreads + threadIdx.x;
-        if (i < r.hi) {
-            const u32 d = doc_ids[i];
-            accb[d] = accb[d] + impacts[i];
-        }
+        const bool ok = i < r.hi;
+        d[j] = ok ? doc_ids[i] : 0xFFFFFFFFu;
+        im[j] = ok ? impacts[i] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < kTaatPerThread; ++j) a[j] = d[j] != 0xFFFFFFFFu ? accb[d[j]] : 0.f;
+#pragma unroll
+    for (int j = 0; j < kTaatPerThread; ++j)
+        if (d[j] != 0xFFFFFFFFu) accb[d[j]] = a[j] + im[j];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tiled TAAT (the default path, k <= 64): one workgroup per (document tile, query) keeps the tile's fp32 accumulators in
+// LDS (16384 documents = 64 KiB), walks the query's term slots IN ORDER -- for each slot it streams only the postings
+// whose document falls into the tile -- and then selects the tile's top-k straight out of LDS.  HBM traffic is the posting
+// streams alone: no accumulator array to zero, scatter into and scan again (the global-accumulator form below moves
+// 8 B per posting plus up to two 128-B lines per touched accumulator through L2, and ran at ~1.2 TB/s).
+// Where a list's tile range starts comes from a SKIP TABLE built at create time for every list with >= kSkipMinDf
+// postings (the posting offset at each tile boundary, u32 relative to the list start, (ntiles + 1) entries); shorter
+// lists are read whole by every tile and filtered -- 61 tiles x < 2048 postings costs less than a table lookup chain.
+// Determinism: a document occurs at most once per list, so within a slot no two threads touch the same accumulator and
+// the barrier between slots keeps every document's fp32 sum in query-term order, exactly the oracle's.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kTileDocs = 16384;
+constexpr u64 kSkipMinDf = 2048;
+constexpr int kMaxSlots = 64;      // query terms the tiled kernel takes (longer queries use the global-accumulator form)
+
+struct TileSlot {   // posting range of one (query, term slot); skip = first entry of the list's skip table or -1
+    unsigned long long lo, hi;
+    long long skip;
+};
+
+__global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ doc_ids, const float* __restrict__ impacts,
+                                                        const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
+                                                        const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
+                                                        u64* __restrict__ ck, i64* __restrict__ ci,
+                                                        unsigned long long* __restrict__ dbg)
+{
+    extern __shared__ float tacc[];  // kTileDocs accumulators
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x, q = blockIdx.y;
+    const u32 tlo = (u32)tile * kTileDocs;
+    const u32 tlen = (u32)min((i64)kTileDocs, n_docs - (i64)tlo);
+    unsigned long long* dp = dbg ? dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    if (dp && threadIdx.x == 0) dp[0] = wall_clock64();
+    // posting ranges of this tile for every slot, resolved up front (slot descriptor -> skip table is a chain of two
+    // dependent global loads; done per slot inside the loop it cost ~4 us of latency six times per workgroup)
+    __shared__ unsigned long long ra[kMaxSlots], rb[kMaxSlots];
+    const int ns = min(nslots[q], kMaxSlots);
+    if (tid < ns) {
+        const TileSlot sl = slots[(i64)q * max_slots + tid];
+        u64 a = sl.lo, b = sl.hi;
+        if (sl.skip >= 0) {
+            a = sl.lo + skip[sl.skip + tile];
+            b = sl.lo + skip[sl.skip + tile + 1];
+        }
+        ra[tid] = a;
+        rb[tid] = b;
+    }
+    for (int i = tid; i < kTileDocs / 4; i += 256) reinterpret_cast<float4*>(tacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (dp && tid == 0) dp[1] = wall_clock64();
+    // The slots form ONE stream of 2048-posting chunks: the loads of the next chunk -- of the same slot or of the next
+    // one -- are in flight while this chunk's accumulator updates run; a workgroup barrier separates slots only.
+    constexpr int U = 8;
+    constexpr u64 CH = (u64)U * 256;
+    auto fetch = [&](u64 i0, u64 b, u32 (&d)[U], float (&im)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {   // eight independent 1 KiB-per-instruction loads of each stream
+            const u64 i = i0 + (u64)j * 256 + tid;
+            const bool ok = i < b;
+            d[j] = ok ? doc_ids[i] - tlo : 0xFFFFFFFFu;
+            im[j] = ok ? impacts[i] : 0.f;
+        }
+    };
+    int cs = 0;              // cursor: next chunk to fetch = [cpos, ..) of slot cs
+    u64 cpos = ns > 0 ? ra[0] : 0;
+    auto next_chunk = [&](int& slot, u64& pos, u64& bound) -> bool {
+        while (cs < ns && cpos >= rb[cs]) { ++cs; if (cs < ns) cpos = ra[cs]; }
+        if (cs >= ns) return false;
+        slot = cs; pos = cpos; bound = rb[cs];
+        cpos += CH;
+        return true;
+    };
+    u32 dA[U], dB[U];
+    float mA[U], mB[U];
+    int sA = 0, sB = 0;
+    u64 pA = 0, pB = 0, bA = 0, bB = 0;
+    bool haveA = next_chunk(sA, pA, bA);
+    if (haveA) fetch(pA, bA, dA, mA);
+    while (haveA) {
+        const bool haveB = next_chunk(sB, pB, bB);
+        if (haveB) fetch(pB, bB, dB, mB);
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (dA[j] < tlen) tacc[dA[j]] += mA[j];
+        if (!haveB || sB != sA) __syncthreads();   // slot boundary: later slots add to the same documents
+#pragma unroll
+        for (int j = 0; j < U; ++j) { dA[j] = dB[j]; mA[j] = mB[j]; }
+        sA = sB; pA = pB; bA = bB;
+        haveA = haveB;
+    }
+    __syncthreads();
+    if (dp && tid == 0) dp[2] = wall_clock64();
+    // ---- tile top-K1 out of LDS: wave w filters accumulators [4096 w, 4096 (w + 1)) like select_wave_kernel<true> ----
+    constexpr int NV = 16;
+    float v[NV * 4];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const float4 x = reinterpret_cast<const float4*>(tacc)[wv * 1024 + it * 64 + lane];
+        v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NV * 4; ++n) m = fmaxf(m, v[n] > 0.f ? v[n] : -INFINITY);
+    const u32 mo = m == -INFINITY ? 0u : ord32(m);
+    u32 best = 0;
+    for (int j = 0; j < 64; ++j) {
+        const u32 mj = (u32)__builtin_amdgcn_readlane((int)mo, j);
+        const int cnt = __popcll(__ballot(mo >= mj));
+        if (mj != 0 && cnt >= K1 && mj > best) best = mj;
+    }
+    if (best) {
+#pragma unroll
+        for (int n = 0; n < NV * 4; ++n) v[n] = v[n] > 0.f ? v[n] : -INFINITY;
+        u32 top = mo;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) top = max(top, (u32)__shfl_xor((int)top, off));
+        best = wave_bisect_threshold(v, best, top + 1, K1, 10);
+    }
+    if (dp && tid == 0) dp[3] = wall_clock64();
+    WaveListPacked L;
+    L.init();
+    u64 tau = best ? ((u64)best << 32) - 1 : 0;
+#pragma unroll
+    for (int n = 0; n < NV * 4; ++n) {
+        const u32 local = (u32)wv * 4096u + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+        u64 c = 0;
+        if (v[n] > 0.f && local < tlen) c = pack_key(v[n], tlo + local);
+        tau = L.offer(c, K1, tau);
+    }
+    if (lane < K1) {
+        const i64 o = (((i64)q * gridDim.x + tile) * 4 + wv) * K1 + lane;
+        ck[o] = L.e & 0xFFFFFFFF00000000ull;
+        ci[o] = L.e ? (i64)packed_index(L.e) : -1;
+    }
+    if (dp && tid == 0) dp[4] = wall_clock64();
 }
 
 struct FinishArgs {
@@ -87,10 +235,15 @@ struct Bm25Index {
     int device = 0;
     i64 n_docs = 0, n_terms = 0, n_postings = 0, id_base = 0;
     std::vector<uint64_t> offsets;  // host copy: planning happens on the host
-    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid;
+    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg;
+    std::vector<i64> skip_index;         // per term: first entry of its skip table, or -1 (short lists)
+    std::vector<TileSlot> plan_slots;    // host staging of the last query plan (kept alive for the async copy)
+    std::vector<int> plan_nslots;
+    bool force_global = false;           // HIPBM25_GLOBAL_ACC=1: the global-accumulator form for every k (A/B runs)
     int ws_k = 0;
     i64 queries = 0, postings_touched = 0, bytes_alg = 0;
 
+    i64 ntiles() const { return std::max<i64>(1, (n_docs + kTileDocs - 1) / kTileDocs); }
     i64 nchunks() const { return std::max<i64>(1, (n_docs + kTile - 1) / kTile); }
     i64 stride() const { return std::max<i64>(4, (n_docs + 3) / 4 * 4); }       // accumulator row stride (16-B aligned rows)
     i64 nlists() const { return (std::max<i64>(1, (n_docs + kSelPerWave - 1) / kSelPerWave) + 3) / 4 * 4; }
@@ -108,11 +261,86 @@ struct Bm25Index {
         return HIPRAG_OK;
     }
 
+    // tiled path: the whole query batch in one TAAT launch + one merge launch
+    int32_t search_tiled(const uint32_t* terms, const int32_t* qoff, int nq, int k, double* o64p, float* o32p, i64* oidp,
+                         hipStream_t st)
+    {
+        int32_t rc;
+        int max_slots = 1;
+        for (int b = 0; b < nq; ++b) max_slots = std::max(max_slots, qoff[b + 1] - qoff[b]);
+        HR_CHECK_HIP(hipStreamSynchronize(st));   // the previous call's plan copy must have left the staging vectors
+        plan_slots.assign((size_t)nq * max_slots, TileSlot{0, 0, -1});
+        plan_nslots.assign((size_t)nq, 0);
+        for (int b = 0; b < nq; ++b) {
+            const int nt = qoff[b + 1] - qoff[b];
+            plan_nslots[b] = nt;
+            for (int s = 0; s < nt; ++s) {
+                const uint32_t t = terms[qoff[b] + s];
+                TileSlot& sl = plan_slots[(size_t)b * max_slots + s];
+                if ((i64)t < n_terms) { sl.lo = offsets[t]; sl.hi = offsets[t + 1]; sl.skip = skip_index[t]; }  // unknown terms score nothing
+                postings_touched += (i64)(sl.hi - sl.lo);
+                bytes_alg += (i64)(sl.hi - sl.lo) * 8;
+            }
+        }
+        const i64 lists = ntiles() * 4;
+        unsigned long long* dbg_p = nullptr;
+        if (getenv("HIPBM25_DEBUG_PHASES")) {
+            if ((rc = dbg.reserve((size_t)nq * ntiles() * 64))) return rc;
+            dbg_p = dbg.as<unsigned long long>();
+        }
+        if ((rc = slots_dev.reserve(plan_slots.size() * sizeof(TileSlot)))) return rc;
+        if ((rc = nslots_dev.reserve(plan_nslots.size() * sizeof(int)))) return rc;
+        if ((rc = ck.reserve((size_t)nq * lists * k * sizeof(u64)))) return rc;
+        if ((rc = ci.reserve((size_t)nq * lists * k * sizeof(i64)))) return rc;
+        HR_CHECK_HIP(hipMemcpyAsync(slots_dev.p, plan_slots.data(), plan_slots.size() * sizeof(TileSlot), hipMemcpyHostToDevice, st));
+        HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots.data(), plan_nslots.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kTileDocs * (int)sizeof(float)));
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL(taat_tile_kernel, dim3((unsigned)ntiles(), nq), dim3(256), kTileDocs * sizeof(float), st,
+                           doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
+                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), dbg_p);
+        if (dbg_p) {
+            HR_CHECK_HIP(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h((size_t)nq * ntiles() * 8);
+            HR_CHECK_HIP(hipMemcpy(h.data(), dbg_p, h.size() * 8, hipMemcpyDeviceToHost));
+            double ph[4] = {0, 0, 0, 0};
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t w = 0; w < (size_t)nq * ntiles(); ++w) {
+                for (int p = 0; p < 4; ++p) ph[p] += (double)(h[w * 8 + p + 1] - h[w * 8 + p]);
+                t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 4]);
+            }
+            const double n = (double)nq * ntiles(), us = 1e-2;   // 100 MHz wall clock
+            fprintf(stderr, "[hipbm25] per workgroup (us): ranges+zero %.1f | stream %.1f | threshold %.1f | inserts %.1f ; kernel wall %.1f us, %lld workgroups\n",
+                    ph[0] / n * us, ph[1] / n * us, ph[2] / n * us, ph[3] / n * us, (double)(t1 - t0) * us, (long long)n);
+        }
+        const i64 wave_cand = lists * k;
+        const i64 per_lane = (wave_cand + 1023) / 1024;
+        auto mk = merge_packed_kernel<16>;
+        if (per_lane <= 1) mk = merge_packed_kernel<1>;
+        else if (per_lane <= 2) mk = merge_packed_kernel<2>;
+        else if (per_lane <= 4) mk = merge_packed_kernel<4>;
+        else if (per_lane <= 8) mk = merge_packed_kernel<8>;
+        hipLaunchKernelGGL(mk, dim3(nq), dim3(1024), 0, st, (const u64*)ck.as<u64>(), (const i64*)ci.as<i64>(), wave_cand, k, id_base,
+                           o64p, o32p, oidp);
+        HR_CHECK_HIP(hipGetLastError());
+        queries += nq;
+        bytes_alg += (i64)nq * n_docs * 8;   // SURVEY 8d counts the accumulator zero + scan passes; this path keeps them in LDS
+        return HIPRAG_OK;
+    }
+
     int32_t search_dev(const uint32_t* terms, const int32_t* qoff, int nq, int k, double* o64p, float* o32p, i64* oidp,
                        hipStream_t st)
     {
-        int32_t rc = reserve(k);
-        if (rc) return rc;
+        int32_t rc;
+        int longest = 0;
+        for (int b = 0; b < nq; ++b) longest = std::max(longest, qoff[b + 1] - qoff[b]);
+        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * 4 * k <= 16 * 64 * 16)
+            return search_tiled(terms, qoff, nq, k, o64p, o32p, oidp, st);
+        if ((rc = reserve(k))) return rc;
         for (int q0 = 0; q0 < nq; q0 += kBatch) {
             const int m = std::min(kBatch, nq - q0);
             int max_terms = 0;
@@ -211,6 +439,11 @@ int32_t hipbm25_create(int64_t n_docs, int64_t n_terms, const uint64_t* offsets_
     HR_REQUIRE(P == 0 || (doc_ids_host && impacts_host), "null postings");
     for (uint64_t i = 0; i < P; ++i)
         HR_REQUIRE((int64_t)doc_ids_host[i] < n_docs, "posting %llu has doc id %u >= n_docs", (unsigned long long)i, doc_ids_host[i]);
+    // every list strictly ascending by document: one posting per (term, document) is what makes the atomics-free
+    // accumulation deterministic, and the skip tables are built by binary search
+    for (int64_t t = 0; t < n_terms; ++t)
+        for (uint64_t i = offsets_host[t] + 1; i < offsets_host[t + 1]; ++i)
+            HR_REQUIRE(doc_ids_host[i - 1] < doc_ids_host[i], "posting list of term %lld is not strictly ascending by doc id", (long long)t);
     auto ix = std::make_shared<Bm25Index>();
     ix->device = device;
     ix->n_docs = n_docs;
@@ -224,6 +457,28 @@ int32_t hipbm25_create(int64_t n_docs, int64_t n_terms, const uint64_t* offsets_
     if (P) {
         HR_CHECK_HIP(hipMemcpy(ix->doc_ids.p, doc_ids_host, P * sizeof(u32), hipMemcpyHostToDevice));
         HR_CHECK_HIP(hipMemcpy(ix->impacts.p, impacts_host, P * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // skip tables of the long lists (taat_tile_kernel): posting offset at every tile boundary, relative to the list start
+    {
+        const i64 nt = ix->ntiles();
+        ix->skip_index.assign((size_t)n_terms, -1);
+        std::vector<u32> skip;
+        for (int64_t t = 0; t < n_terms; ++t) {
+            const uint64_t lo = offsets_host[t], hi = offsets_host[t + 1];
+            if (hi - lo < kSkipMinDf) continue;
+            HR_REQUIRE(hi - lo < (1ull << 32), "posting list of term %lld is too long for u32 skip offsets", (long long)t);
+            ix->skip_index[(size_t)t] = (i64)skip.size();
+            const uint32_t* b = doc_ids_host + lo;
+            const uint32_t* e = doc_ids_host + hi;
+            for (i64 tile = 0; tile <= nt; ++tile) {
+                const uint64_t bound = (uint64_t)tile * kTileDocs;
+                skip.push_back((u32)(std::lower_bound(b, e, bound, [](uint32_t d, uint64_t v) { return (uint64_t)d < v; }) - b));
+            }
+        }
+        if ((rc = ix->skip_dev.reserve(std::max<size_t>(16, skip.size() * sizeof(u32))))) return rc;
+        if (!skip.empty()) HR_CHECK_HIP(hipMemcpy(ix->skip_dev.p, skip.data(), skip.size() * sizeof(u32), hipMemcpyHostToDevice));
+        const char* fg = getenv("HIPBM25_GLOBAL_ACC");
+        ix->force_global = fg && fg[0] == '1';
     }
     *out_handle = reg().put(ix);
     return HIPRAG_OK;

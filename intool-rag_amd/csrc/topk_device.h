@@ -299,6 +299,27 @@ __device__ __forceinline__ void wave_topk_packed(const u64 (&c)[N], int K, WaveL
     for (int n = 0; n < N; ++n) tau = L.offer(c[n], K, tau);
 }
 
+// Tighten a wave-wide selection threshold by bisection in the ordered-integer domain.  On entry at least K of the wave's
+// N * 64 values v (excluded ones are -inf) are >= unord32(lo) and fewer than K are >= unord32(hi); on exit lo has moved up
+// so that the count is still >= K but close to it.  Why: the lane-maxima threshold of the selectors (K-th largest of 64
+// lane maxima) lets through several hundred of 4096 values when K is 33-50, and every one of them costs a serial
+// sorted-list insertion (~100 cycles); ten bisection steps cost ~600 cycles each and cut the insertions to about K.
+template <int N>
+__device__ __forceinline__ u32 wave_bisect_threshold(const float (&v)[N], u32 lo, u32 hi, int K, int steps)
+{
+    for (int s = 0; s < steps && hi - lo > 1; ++s) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        const float t = unord32(mid);
+        int c = 0;   // wave-wide count, kept on the scalar unit: one v_cmp per value, s_bcnt1 + s_add beside it
+#pragma unroll
+        for (int n = 0; n < N; ++n) c += __popcll(__ballot(v[n] >= t));
+        if (c >= K) lo = mid;
+        else hi = mid;
+        if (c >= K && c <= K + (K >> 1)) break;   // close enough: the sorted-list stage takes the rest
+    }
+    return lo;
+}
+
 // Level-1 selector, K1 <= 64: grid (nslices, nq), 256 threads = 4 independent waves; wave w of slice s filters the
 // contiguous kSelPerWave elements [(4s+w)*kSelPerWave, ...) of query q's float array (all loads issued up-front) and
 // writes its sorted top-K1 as (key = ord32(v) << 32, id = index) to ck/ci[q][(4s+w)*K1 ..].
@@ -344,6 +365,16 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const float* __restric
         const u32 mj = (u32)__builtin_amdgcn_readlane((int)mo, j);
         const int cnt = __popcll(__ballot(mo >= mj));
         if (mj != 0 && cnt >= K1 && mj > best) best = mj;
+    }
+    if (best) {
+        if (POSITIVE_ONLY) {
+#pragma unroll
+            for (int n = 0; n < NV * 4; ++n) v[n] = v[n] > 0.f ? v[n] : -INFINITY;
+        }
+        u32 top = mo;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) top = max(top, (u32)__shfl_xor((int)top, off));
+        best = wave_bisect_threshold(v, best, top + 1, K1, 10);
     }
     // elements with ord32(v) >= best can still be among the top K1; everything else is rejected by one compare
     WaveListPacked L;
