@@ -306,3 +306,37 @@ def test_ingest_indexing_then_retrieval_config1_scale(gpu, tmp_path, monkeypatch
         fac.set_embedding_provider(None)
         hi.clear_caches()
         clear_sparse_cache()
+
+
+def test_bm25_tiled_and_global_accumulator_forms_agree_with_the_oracle(gpu, monkeypatch):
+    """Five document tiles (the last one partial), lists long enough for skip tables and short ones that every tile
+    filters; k = 64 is the last k of the tiled form, k = 65 and a 70-term query take the global-accumulator form, which
+    HIPBM25_GLOBAL_ACC=1 also forces for the first case.  All of them: ids and fp32 scores equal to the oracle's."""
+    from hiprag import HipBM25, PostingsCSR, HipRagError
+    n_docs, n_terms = 70001, 2048
+    p = ho.synthetic_postings(n_docs, n_terms=n_terms, seed=31)
+    df = np.diff(p.offsets)
+    assert df.max() >= 2048 and (df[df > 0].min() < 2048)
+    queries = ho.synthetic_sparse_queries(21, n_terms=n_terms, terms_per_query=6, seed=32, min_rank=4)
+    queries[2] = np.arange(3, 73, dtype=np.uint32)                       # 70 terms
+    queries[7] = np.asarray([0, 1, 2, 0], dtype=np.uint32)               # the three longest lists, one of them twice
+    short = [q for i, q in enumerate(queries) if i != 2]
+    for k in (10, 64, 65):
+        es, ei = ho.bm25_search(p, short, k)
+        s, i = HipBM25(_gpu_postings(p)).search(short, k)
+        assert np.array_equal(i, ei) and np.array_equal(s, es), k
+    es, ei = ho.bm25_search(p, queries, 10)
+    s, i = HipBM25(_gpu_postings(p)).search(queries, 10)                 # the 70-term query sends the batch the other way
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    monkeypatch.setenv("HIPBM25_GLOBAL_ACC", "1")
+    s, i = HipBM25(_gpu_postings(p)).search(short, 10)
+    es, ei = ho.bm25_search(p, short, 10)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    monkeypatch.delenv("HIPBM25_GLOBAL_ACC")
+    # lists must be strictly ascending by document: the skip tables and the atomics-free accumulation rely on it
+    bad = p.doc_ids.copy()
+    t = int(np.argmax(df))
+    lo = int(p.offsets[t])
+    bad[lo], bad[lo + 1] = bad[lo + 1], bad[lo]
+    with pytest.raises(HipRagError, match="ascending"):
+        HipBM25(PostingsCSR(p.n_docs, p.n_terms, p.offsets, bad, p.impacts))
