@@ -264,7 +264,7 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
     }
 }
 
-template <int METRIC, int NWAVES, int VARIANT, int RING = 16>
+template <int METRIC, int NWAVES, int RING = 16>
 __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P][64] query fragments: lane = h*32 + b holds Q[b][8p + 4h + 0..3]
@@ -335,15 +335,10 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
                 int nx = pp + i + 1;
                 nx = nx == P ? 0 : nx;
                 bnext = qs[nx * kPieceVec4 + lane];
-                if (VARIANT != 6 && VARIANT != 7) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
-                else asm volatile("" ::"v"(av[0]));
-                if (VARIANT != 1 && VARIANT != 6 && VARIANT != 7) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
-                } else {
-                    asm volatile("" ::"v"(av[1]), "v"(av[2]), "v"(av[3]));
-                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
                 const unsigned voff = lane16 + (unsigned)min(s + RING + i, S - 1) * 1024u;
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(ring[i]) : "v"(voff), "s"(base) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -412,7 +407,7 @@ __global__ __launch_bounds__(256) void qprep_split_kernel(const float* __restric
     qf[npairs * 64 + idx] = lo;
 }
 
-template <int METRIC, int NWAVES, int RING = 16, int VARIANT = 0, int QT = 1, int CH = kChunk, bool MULTI = true>
+template <int METRIC, int NWAVES, int RING = 16, int QT = 1, int CH = kChunk, bool MULTI = true>
 __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];  // [P/2][64] hi fragments, then [P/2][64] lo fragments (16 B each)
@@ -569,17 +564,10 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = acc_hi[i] + acc_lo[i];
-            if (VARIANT == 20) {  // timing experiment: no group-max store at all
-                float t = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t += acc[i];
-                if (t == 123.456f) a.gmax[0] = t;
-            } else {
-                float sec;
-                const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
-                park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-                park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
-            }
+            float sec;
+            const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
+            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
+            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
         } else {
             float sec;
             float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h, a, sec);
@@ -1110,7 +1098,6 @@ struct DenseIndex {
     int n_cu = 256;
     int scan_cus = 256;       // workgroups of a scan launch (one per CU); HIPRAG_SCAN_SPARE_CUS leaves some CUs to the tails
     int scan_mode = 2;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo, 32 q/pass), q64 = 2 (default)
-    int scan_variant = 0;     // HIPRAG_SCAN_VARIANT: timing experiments only
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
     struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0, chunk = kChunk; int k = 0; int64_t blocks = 0; int ev_idx = -1; };
@@ -1151,8 +1138,6 @@ struct DenseIndex {
         scan_cus = std::max(1, n_cu - (sp ? atoi(sp) : (n_cu >= 64 ? 8 : 0)));
         const char* ms = getenv("HIPRAG_SCAN_MODE");
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
-        const char* vs = getenv("HIPRAG_SCAN_VARIANT");
-        scan_variant = vs ? atoi(vs) : 0;
         const char* lq = getenv("HIPRAG_LAUNCH_QUERIES");
         launch_q = lq ? atoi(lq) : kMaxQ;
         launch_q = std::max(pass_queries(), std::min(kMaxQ, launch_q / pass_queries() * pass_queries()));
@@ -1288,20 +1273,17 @@ struct DenseIndex {
         if (split) {
             void (*scan)(ScanArgs) = scan_split_kernel<METRIC, 8>;
             const bool one_pass = nq <= pass_queries_for(k);
-            if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 1, kChunk, false>;
+            if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 1, kChunk, false>;
             if (mode == 2) {                                                             // 64 queries, hi-only query tiles
-                scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8>; w.chunk = 8;
-                if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 0, 2, 8, false>;
-            } else if (scan_variant == 20) scan = scan_split_kernel<METRIC, 8, 16, 20>;   // timing experiment only
+                scan = scan_split_kernel<METRIC, 8, 16, 2, 8>; w.chunk = 8;
+                if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 2, 8, false>;
+            }
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(scan_cus), dim3(8 * 64), scan_lds, st, sa);
         } else {
-            const int variant = scan_variant;  // timing experiments only (variants 1 and 6 give wrong scores)
             int NW = 8;
-            void (*scan)(ScanArgs) = scan_kernel<METRIC, 8, 0>;
-            if (variant == 1) scan = scan_kernel<METRIC, 8, 1>;
-            if (variant == 6) scan = scan_kernel<METRIC, 8, 6>;
+            void (*scan)(ScanArgs) = scan_kernel<METRIC, 8>;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((P * kPieceVec4 + 255) / 256)), dim3(256), 0, st, q_dev, nq, d, P,
                                w.qf.as<float4>());
