@@ -8,9 +8,10 @@ comparator is (score, id), the sharded result equals the unsharded one bit for b
 The reference is a single CPU process: this is new capability, not a port of anything.
 
 Pipelining.  The index scan is the only HBM-heavy stage; selection, re-scoring, the exchange and the merge are
-latency-bound.  `search_begin` therefore enqueues the scan on the caller's stream and everything after it on a
-side stream (two workspace slots in the library), so that with one batch in flight the tail of batch i runs beside
-the scan of batch i+1.  `search_end` makes the caller's stream wait for the batch's result.
+latency-bound.  `search_begin` therefore enqueues the scan (one launch of up to `launch_queries` queries = several
+passes over the local rows) on the caller's stream and everything after it on the stream of one of eight workspace
+slots, so that the tails of earlier batches run beside later scans -- on the CUs the scan grid leaves free.
+`search_end` enqueues the merge of the gathered partial lists and makes the caller's stream wait for the result.
 """
 from __future__ import annotations
 
@@ -68,6 +69,8 @@ class ShardedFlatIndex:
         key = (nq, k)
         cache = self._bufs[slot]
         if cache.get("key") != key:
+            if self._slot_used[slot]:
+                self.side[slot].synchronize()     # kernels of the slot's previous shape may still read the old buffers
             cache.clear()
             cache["key"] = key
             cache["pack"] = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
