@@ -270,3 +270,72 @@ def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
     p2 = ix.stats()["passes"]
     assert (p1 - p0, p2 - p1) == (4, 2)          # 100 queries: 4 passes of 32, then 2 passes of 64
     assert ix.stats()["fallback_queries"] == 0
+
+
+def test_full_size_1m_x_1024_properties(gpu):
+    """BASELINE configs[1] at full size (1M x 1024, top-10), where the CPU oracle would take minutes: size-independent
+    properties instead -- (a) 256 planted queries (row + 5 % noise) find their row first, (b) every result list is sorted by
+    (score desc, id asc) and repeats bit for bit, (c) eight row shards merged == the unsharded index bit for bit,
+    (d) the top-10 of 8 queries equals an independent fp64 ranking computed chunk by chunk with torch on the GPU."""
+    import torch
+    from hiprag import HipFlatIndex, merge_topk_device
+    N, d, k, chunk = 1_000_000, 1024, 10, 125_000
+    dev = torch.device("cuda", 0)
+
+    def rows_of(c):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + c)
+        x = torch.randn((chunk, d), generator=g, device=dev, dtype=torch.float32)
+        return x / x.norm(dim=1, keepdim=True)
+
+    full = HipFlatIndex(d, ho.METRIC_IP)
+    shards = []
+    for c in range(N // chunk):
+        x = rows_of(c)
+        full.add_device(x)
+        sh = HipFlatIndex(d, ho.METRIC_IP)
+        sh.add_device(x)
+        sh.set_id_base(c * chunk)
+        shards.append(sh)
+    assert full.ntotal == N
+    # (a) planted neighbours
+    planted = torch.arange(256, device=dev) * 3907 + 11
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    src = torch.cat([rows_of(int(p) // chunk)[int(p) % chunk][None] for p in planted.tolist()])
+    noise = torch.randn(src.shape, generator=g, device=dev)
+    q = src + 0.05 * noise / noise.norm(dim=1, keepdim=True)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    s64, s32, ids = full.search_device(q, k)
+    torch.cuda.synchronize()
+    assert torch.equal(ids[:, 0], planted)
+    # (b) canonical order, determinism
+    sc, idn = s64.cpu().numpy(), ids.cpu().numpy()
+    assert np.all((sc[:, :-1] > sc[:, 1:]) | ((sc[:, :-1] == sc[:, 1:]) & (idn[:, :-1] < idn[:, 1:])))
+    s64b, _, idsb = full.search_device(q, k)
+    torch.cuda.synchronize()
+    assert torch.equal(idsb, ids) and torch.equal(s64b, s64)
+    # (c) 8 row shards + canonical merge == unsharded, bit for bit
+    ps, pi = [], []
+    for sh in shards:
+        a, _, b = sh.search_device(q, k)
+        ps.append(a.clone())
+        pi.append(b.clone())
+    m64, _, mids = merge_topk_device(torch.stack(ps), torch.stack(pi), k, ho.METRIC_IP)
+    torch.cuda.synchronize()
+    assert torch.equal(mids, ids) and torch.equal(m64, s64)
+    # (d) independent fp64 ranking of 8 queries
+    q8 = q[:8].double()
+    best_s = torch.full((8, 0), 0.0, dtype=torch.float64, device=dev)
+    best_i = torch.zeros((8, 0), dtype=torch.int64, device=dev)
+    for c in range(N // chunk):
+        sc_c = q8 @ rows_of(c).double().T                                   # [8, chunk] fp64
+        ts, ti = torch.topk(sc_c, k, dim=1)
+        best_s = torch.cat([best_s, ts], 1)
+        best_i = torch.cat([best_i, ti + c * chunk], 1)
+    order = torch.argsort(best_s, dim=1, descending=True, stable=True)[:, :k]
+    ref_i = torch.gather(best_i, 1, order)
+    ref_s = torch.gather(best_s, 1, order)
+    assert torch.equal(ref_i, ids[:8])
+    assert torch.allclose(ref_s, s64[:8], rtol=0, atol=1e-12)
+    assert full.stats()["fallback_queries"] == 0
