@@ -15,7 +15,7 @@
 //   K6/K8/K9 gemm_bf16_kernel 128x128x64 LDS-tiled GEMM, C = A[M,K] * W[N,K]^T, fused epilogues:
 //            QKV (bias, 1/8 scale on q, head-major q/k and TRANSPOSED v), GELU (bias + erf-GELU), RESID (bias + residual
 //            -> fp32 pre-LayerNorm buffer)
-//   K7  attention_kernel     flash-style: 64 queries x 64-key tiles, online softmax in fp32, P through LDS
+//   K7  attention_kernel     flash-style, computed transposed: 128 queries x 64-key tiles, online softmax in fp32, P stays in registers
 //       layernorm_kernel     fp32 pre-LN rows -> bf16
 //   K10 pool_kernel / rerank_head_kernel
 // LDS tiles are stored k-chunk-major ([k/8][row][8 bf16]) with row ^= (chunk & 7): fragment reads (ds_read_b128) and
@@ -304,8 +304,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ t
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K7: attention.  grid (S/64, heads, nseq); 4 waves x 16 query rows; keys in tiles of 64.
+// K7: attention.  grid (ceil(S/128), heads, nseq); 4 waves x 32 queries; keys in tiles of 64.
 // q,k: [nseq, heads, S, 64] (q pre-scaled by 1/8), vt: [nseq, heads, 64, S]; ctx out: [M, H] row-major.
+// Everything is computed TRANSPOSED so that the probabilities never leave registers:
+//   S^T tile  D[key 4kq + r][query r16] = K fragment (A operand, from LDS) x Q fragment (B operand, registers)
+//   O^T      D[d   4kq + r][query r16] += V^T fragment (A, from LDS) x P^T fragment (B) -- and the B operand of a 32-key
+//            slab is exactly what the lane already holds of two S^T tiles: keys 32s + 4kq + 0..3 and 32s + 16 + 4kq + 0..3.
+//            The contraction order inside an MFMA is free as long as A and B agree, so the V^T fragment is read as those
+//            two 8-byte key groups instead of one 16-byte run.
+// A lane therefore owns ONE query column: running max / sum are per-lane scalars (two xor-shuffles across the kq lanes
+// per tile), and the output is 4 consecutive d per lane -> 8-byte stores.  K / V^T tiles are fetched into registers one
+// tile ahead (global latency under the MFMAs) and written to LDS between two barriers.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ vt, const int* __restrict__ lens,
@@ -313,10 +322,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 {
     __shared__ bf16x8 kl[64 * 8];        // K tile  [d/8][key][8], swizzled
     __shared__ bf16x8 vl[64 * 8];        // V^T tile [key/8][d][8], swizzled
-    __shared__ bf16 pl[4][16][72];       // per-wave P [q][key], rows padded to 144 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int seq = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
+    const int seq = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
     const int len = lens[seq];
     if (q0 >= len) return;  // whole query tile is padding
     const size_t hb = (size_t)seq * heads + head;
@@ -324,102 +332,122 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const bf16* kh = k + hb * S * 64;
     const bf16* vh = vt + hb * 64 * S;
 
-    bf16x8 qf[2];
+    // Q fragments (B operand): lane (query r16, kq) holds Q[query][32 ks + 8 kq .. +7]; two query tiles per wave
+    bf16x8 qf[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(qh + (size_t)(q0 + wave * 16 + r16) * 64 + ks * 32 + kq * 8);
-
-    f32x4 o[4];
+    for (int t = 0; t < 2; ++t) {
+        const int qi = min(q0 + wave * 32 + t * 16 + r16, S - 1);   // S is a multiple of 64, the tile covers 128
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
+        for (int ks = 0; ks < 2; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qi * 64 + ks * 32 + kq * 8);
+    }
+    f32x4 o[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
     const float LOG2E = 1.4426950408889634f;
 
-    for (int kt0 = 0; kt0 < len; kt0 += 64) {
-        __syncthreads();  // previous tile fully consumed
-        // stage K [64 keys][64 d] and V^T [64 d][64 keys]: 512 chunks each, 2 per thread
+    // tile prefetch registers: 512 16-B chunks per operand tile, 2 per thread
+    bf16x8 pk[2], pv[2];
+    auto prefetch = [&](int kt0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i;
             const int row = c >> 3, kc = c & 7;
-            kl[swz_unit(kc, row, 64)] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kt0 + row) * 64 + kc * 8);
-            vl[swz_unit(kc, row, 64)] = *reinterpret_cast<const bf16x8*>(vh + (size_t)row * S + kt0 + kc * 8);
+            pk[i] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kt0 + row) * 64 + kc * 8);
+            pv[i] = *reinterpret_cast<const bf16x8*>(vh + (size_t)row * S + kt0 + kc * 8);
+        }
+    };
+    prefetch(0);
+    for (int kt0 = 0; kt0 < len; kt0 += 64) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 3, kc = c & 7;
+            kl[swz_unit(kc, row, 64)] = pk[i];
+            vl[swz_unit(kc, row, 64)] = pv[i];
         }
         __syncthreads();
-        // scores: 16 queries x 64 keys per wave
-        f32x4 sc[4];
+        if (kt0 + 64 < len) prefetch(kt0 + 64);   // in flight under this tile's MFMAs
+        // S^T: sc[t][j][r] = score(key kt0 + 16j + 4kq + r, query tile t column r16)
+        f32x4 sc[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8 k0 = kl[swz_unit(kq, j * 16 + r16, 64)];
+            const bf16x8 k1 = kl[swz_unit(4 + kq, j * 16 + r16, 64)];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kl[swz_unit(ks * 4 + kq, j * 16 + r16, 64)], sc[j], 0, 0, 0);
-        }
-        // sc[j][r] = score(query 4*kq + r, key kt0 + 16j + r16); mask padded keys
-        float tmax[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tmax[r] = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool valid = kt0 + j * 16 + r16 < len;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (!valid) sc[j][r] = -INFINITY;
-                tmax[r] = fmaxf(tmax[r], sc[j][r]);
+            for (int t = 0; t < 2; ++t) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[t][1], a, 0, 0, 0);
             }
         }
+        // mask padded keys, online softmax (one query per lane)
+        bf16x8 pf[2][2];   // P^T fragments: [query tile][key slab of 32]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int off = 1; off <= 8; off <<= 1) tmax[r] = fmaxf(tmax[r], __shfl_xor(tmax[r], off));
-        }
-        float alpha[4], psum[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mn = fmaxf(mrow[r], tmax[r]);  // finite: key 0 of the first tile is always valid
-            alpha[r] = exp2f((mrow[r] - mn) * LOG2E);
-            mrow[r] = mn;
-            psum[r] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f((sc[j][r] - mrow[r]) * LOG2E);
-                psum[r] += p;
-                pl[wave][4 * kq + r][j * 16 + r16] = (bf16)p;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int off = 1; off <= 8; off <<= 1) psum[r] += __shfl_xor(psum[r], off);
-            lrow[r] = lrow[r] * alpha[r] + psum[r];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's P writes have landed (same-wave visibility)
-        __builtin_amdgcn_wave_barrier();
-        // O += P V : A = P[q][key] (from LDS), B = V^T[d][key]
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pl[wave][r16][ks * 32 + kq * 8]);
+        for (int t = 0; t < 2; ++t) {
+            float tmax = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vl[swz_unit(ks * 4 + kq, j * 16 + r16, 64)], o[j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kt0 + j * 16 + 4 * kq + r >= len) sc[t][j][r] = -INFINITY;
+                    tmax = fmaxf(tmax, sc[t][j][r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float mn = fmaxf(mrow[t], tmax);   // finite: key 0 of the first tile is always valid
+            const float alpha = __builtin_amdgcn_exp2f((mrow[t] - mn) * LOG2E);
+            mrow[t] = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f((sc[t][2 * s + h][r] - mn) * LOG2E);
+                        psum += p;
+                        pf[t][s][4 * h + r] = (bf16)p;
+                    }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            lrow[t] = lrow[t] * alpha + psum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][j][r] *= alpha;
         }
+        // O^T += V^T P^T: A fragment of d-tile j, slab s = V^T[d = 16j + r16][keys 32s + 4kq + 0..3, 32s + 16 + 4kq + 0..3]
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                const int d = j * 16 + r16;
+                const bf16x4 lo = reinterpret_cast<const bf16x4*>(&vl[swz_unit(4 * s + (kq >> 1), d, 64)])[kq & 1];
+                const bf16x4 hi = reinterpret_cast<const bf16x4*>(&vl[swz_unit(4 * s + 2 + (kq >> 1), d, 64)])[kq & 1];
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) o[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][s], o[t][j], 0, 0, 0);
+            }
     }
-    // o[j][r] = out(query q0 + wave*16 + 4*kq + r, d = 16j + r16) / l
+    // o[t][j][r] = out(query q0 + wave*32 + 16t + r16, d = 16j + 4kq + r) * l
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wave * 16 + 4 * kq + r;
-        const float inv = 1.f / lrow[r];
-        bf16* dst = ctx + ((size_t)seq * S + qi) * H + head * 64;
+    for (int t = 0; t < 2; ++t) {
+        const int qi = q0 + wave * 32 + t * 16 + r16;
+        if (qi >= S) continue;
+        const float inv = 1.f / lrow[t];
+        bf16* dst = ctx + ((size_t)seq * S + qi) * H + head * 64 + 4 * kq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j * 16 + r16] = (bf16)(o[j][r] * inv);
+        for (int j = 0; j < 4; ++j) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[t][j][r] * inv);
+            *reinterpret_cast<bf16x4*>(dst + j * 16) = v;
+        }
     }
 }
 
@@ -515,7 +543,7 @@ struct Encoder {
             // rows >= T exist only as GEMM padding; the QKV scatter must not write them
             g.M = T;
             hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
-            hipLaunchKernelGGL(attention_kernel, dim3(S / 64, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
+            hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
                                (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
                                heads, H);
             GemmArgs o{};
