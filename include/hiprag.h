@@ -109,7 +109,9 @@ typedef struct hipidx_stats {
     int64_t launches;          /* scan kernel launches so far (each runs 1..launch_queries/pass_queries passes back to back) */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
-int32_t hipidx_enable_timing(uint64_t h, int32_t on); /* HIP events around each scan launch, on its stream; get_stats syncs */
+/* on = n > 0: HIP events (on the launch stream) around every n-th scan launch, in-kernel wall-clock stamps on every launch;
+ * 0 = off.  Two event records cost ~20 us of dispatch bubble between chained launches, hence the sampling.  get_stats syncs. */
+int32_t hipidx_enable_timing(uint64_t h, int32_t on);
 
 /* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
  * in_scores64 / in_ids: n_parts blocks of [nq, k_in] (device), block p starting part_stride ELEMENTS after block

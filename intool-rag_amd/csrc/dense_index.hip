@@ -1266,7 +1266,7 @@ struct DenseIndex {
         w.chunk = kChunk;
         const size_t scan_lds = (size_t)P * 1024;  // the query tile; 32 KiB of the CU's LDS stay free for tail kernels
         const int ev = (int)(ev_count % kEvRing);
-        // HIP events cost two barrier packets per launch on the scan's stream; HIPRAG_TIME_EVERY=n brackets every n-th
+        // HIP events cost two barrier packets per launch on the scan's stream; hipidx_enable_timing(h, n) brackets every n-th
         // launch only (the in-kernel stamps cover every launch either way)
         const bool use_ev = timing && ev_count % ev_every == 0;
         sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * 8 * 2 : nullptr;
@@ -1381,8 +1381,6 @@ struct DenseIndex {
         if (timing && evs.empty()) {
             evs.resize(2 * kEvRing);
             ev_set.assign(kEvRing, 0);
-            const char* te = getenv("HIPRAG_TIME_EVERY");
-            ev_every = te ? std::max(1, atoi(te)) : 1;
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
             int32_t src = stamps.reserve((size_t)kEvRing * scan_cus * 8 * 2 * sizeof(unsigned long long));
             if (src) return src;
@@ -1690,6 +1688,7 @@ int32_t hipidx_enable_timing(uint64_t h, int32_t on)
 {
     GET_INDEX(h);
     ix->timing = on != 0;
+    ix->ev_every = std::max(1, on);
     ix->ev_count = 0;
     return HIPRAG_OK;
 }

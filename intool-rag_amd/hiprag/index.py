@@ -153,8 +153,9 @@ class HipFlatIndex:
         nat.call("hipidx_metric", h.value, ctypes.byref(m))
         return cls(d.value, m.value, device, _handle=h.value)
 
-    def enable_timing(self, on: bool = True) -> None:
-        nat.call("hipidx_enable_timing", self._h, 1 if on else 0)
+    def enable_timing(self, on=True) -> None:
+        """True / 1: HIP events around every scan launch; n > 1: around every n-th launch; False / 0: off."""
+        nat.call("hipidx_enable_timing", self._h, int(on))
 
     def stats(self) -> dict:
         st = nat.HipIdxStats()
