@@ -91,6 +91,11 @@ int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);
 int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+/* Leave n CUs out of the scan grid (default 0, or HIPRAG_SCAN_SPARE_CUS): the 64-query scan fills the register file of
+ * every CU it runs on, so kernels of OTHER streams -- the tails of earlier launches, and at N > 1 the RCCL all-gather,
+ * whose ranks spin until every peer has joined -- otherwise only run between scans.  Alone on a GPU that costs nothing
+ * (0 spare CUs is 2-3 % faster than 8 at 1M rows); row-sharded serving sets 8.  Synchronises the device. */
+int32_t hipidx_set_spare_cus(uint64_t h, int32_t n);
 /* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);
 int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host); /* row as stored (tests, export) */

@@ -1135,7 +1135,7 @@ struct DenseIndex {
         HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const char* sp = getenv("HIPRAG_SCAN_SPARE_CUS");
-        scan_cus = std::max(1, n_cu - (sp ? atoi(sp) : (n_cu >= 64 ? 8 : 0)));
+        scan_cus = std::max(1, n_cu - (sp ? atoi(sp) : 0));
         const char* ms = getenv("HIPRAG_SCAN_MODE");
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
         const char* lq = getenv("HIPRAG_LAUNCH_QUERIES");
@@ -1535,6 +1535,19 @@ int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n)
     return HIPRAG_OK;
 }
 
+int32_t hipidx_set_spare_cus(uint64_t h, int32_t n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(n >= 0 && n < ix->n_cu, "spare CUs must be in 0..%d", ix->n_cu - 1);
+    HR_CHECK_HIP(hipDeviceSynchronize());   // the finish kernels of launches in flight decode slots with the old partition
+    ix->scan_cus = ix->n_cu - n;
+    ix->stamps.release();                   // sized by the scan grid
+    for (hipEvent_t e : ix->evs) (void)hipEventDestroy(e);
+    ix->evs.clear();                        // re-created (with the stamp buffer) by the next enable_timing + search
+    ix->timing = false;
+    return HIPRAG_OK;
+}
+
 int32_t hipidx_reserve_search(uint64_t h, int32_t k)
 {
     GET_INDEX(h);
@@ -1738,6 +1751,32 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             for (int64_t i = 0; i < n; ++i) dsum += (double)(se[(size_t)i].second - se[(size_t)i].first);
             const bool ordered = ix->ev_count <= DenseIndex::kEvRing;
             for (int64_t i = 0; ordered && i + 1 < n; ++i) gsum += (double)((long long)se[(size_t)i + 1].first - (long long)se[(size_t)i].second);
+            if (ix->dbg_on && n > 45) {   // spread of the wave exit times inside one launch (how ragged the static partition ends)
+                const size_t i = 44;
+                std::vector<unsigned long long> ends;
+                for (size_t w = 0; w < per / 2; ++w) ends.push_back(hst[i * per + 2 * w + 1]);
+                std::sort(ends.begin(), ends.end());
+                const double tk = 1e3 / ix->wall_khz, t0 = (double)se[i].first;
+                fprintf(stderr, "[hiprag] launch %zu: wave exits at us after the first wave in: p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n", i,
+                        ((double)ends[ends.size() / 100] - t0) * tk, ((double)ends[ends.size() / 10] - t0) * tk, ((double)ends[ends.size() / 2] - t0) * tk,
+                        ((double)ends[ends.size() * 9 / 10] - t0) * tk, ((double)ends[ends.size() * 99 / 100] - t0) * tk, ((double)ends.back() - t0) * tk);
+            }
+            if (ix->dbg_on && n > 45) {   // the same exits grouped by XCD (workgroup id mod 8) and by wave slot inside the workgroup
+                const size_t i = 44;
+                const double tk = 1e3 / ix->wall_khz, t0 = (double)se[i].first;
+                double bx[8] = {0}, bw[8] = {0}; int cx[8] = {0}, cw[8] = {0};
+                for (size_t w = 0; w < per / 2; ++w) {
+                    const double e = ((double)hst[i * per + 2 * w + 1] - t0) * tk;
+                    if (e < 100) continue;   // waves without blocks
+                    bx[(w / 8) % 8] += e; ++cx[(w / 8) % 8];
+                    bw[w % 8] += e; ++cw[w % 8];
+                }
+                fprintf(stderr, "[hiprag] mean exit by XCD:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", bx[x] / std::max(cx[x], 1));
+                fprintf(stderr, " | by wave slot:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", bw[x] / std::max(cw[x], 1));
+                fprintf(stderr, "\n");
+            }
             if (ix->dbg_on && ordered && ix->dbg_stamps.p) {
                 std::vector<unsigned long long> ds((size_t)n * 8);
                 HR_CHECK_HIP(hipMemcpy(ds.data(), ix->dbg_stamps.p, ds.size() * 8, hipMemcpyDeviceToHost));

@@ -132,6 +132,10 @@ class HipFlatIndex:
         nat.call("hipidx_launch_queries", self._h, ctypes.byref(n))
         return n.value
 
+    def set_spare_cus(self, n: int) -> None:
+        """Leave n CUs out of the scan grid for kernels of other streams (tails, the RCCL all-gather); see hiprag.h."""
+        nat.call("hipidx_set_spare_cus", self._h, int(n))
+
     def reserve_search(self, k: int) -> None:
         nat.call("hipidx_reserve_search", self._h, int(k))
 

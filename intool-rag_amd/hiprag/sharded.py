@@ -52,6 +52,10 @@ class ShardedFlatIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         local.set_id_base(row_lo)
+        if self.world > 1 and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+            # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
+            # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
+            local.set_spare_cus(8)
         self.max_pass = local.launch_queries    # queries per search_begin (see hipidx_launch_queries)
         # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
         # the tail of batch i+1, which cannot start before scan i+1 ends

@@ -339,3 +339,19 @@ def test_full_size_1m_x_1024_properties(gpu):
     assert torch.equal(ref_i, ids[:8])
     assert torch.allclose(ref_s, s64[:8], rtol=0, atol=1e-12)
     assert full.stats()["fallback_queries"] == 0
+
+
+def test_spare_cus_change_the_partition_not_the_results(gpu):
+    """hipidx_set_spare_cus re-partitions the scan (fewer workgroups, other block ranges per wave, other group slots);
+    results stay exact, also for a launch in which some waves have no blocks at all."""
+    from hiprag import HipFlatIndex
+    n, d = 40000, 512
+    x = ho.synthetic_vectors(n, d, seed=61)
+    q = ho.synthetic_queries(130, d, seed=62)
+    ix = HipFlatIndex(d, ho.METRIC_IP)
+    ix.add(x)
+    for spare in (0, 8, 200, 0):
+        ix.set_spare_cus(spare)
+        _check(ix, x, q, 10, ho.METRIC_IP)
+    with pytest.raises(Exception):
+        ix.set_spare_cus(100000)
