@@ -14,8 +14,8 @@ in flight so the latency-bound tail of a step (selection, fp64 re-score, exchang
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel = scan_kernel; achieved = algorithmic bytes per launch (rows_local * d_pad * 4,
-               DESIGN.md) / mean launch duration from HIP events recorded on the launch stream around every 4th
-               scan launch of the timed region (in-kernel wall-clock stamps on every launch beside them); peak 8000 GB/s (MI355X_MICROARCH.md).
+               DESIGN.md) / mean launch duration from HIP events recorded on the launch stream around every scan
+               launch of the timed region (in-kernel wall-clock stamps of the same launches beside them); peak 8000 GB/s (MI355X_MICROARCH.md).
   cpu_baseline the oracle's reference-faithful fp32 twin (one query per call, one thread) timed on this box's host
                cores on a bounded sample, rank 0, N=1 only.  A reported baseline, not the target.
 """
@@ -139,9 +139,11 @@ def main():
 
     run_steps(args.warmup, 0)
     barrier()
-    # HIP events around every 4th scan launch (two event records on the launch stream cost ~20 us of dispatch bubble per
-    # launch: 0.7 % of a step here, 5 % of a step at an 8-way shard); in-kernel stamps cover every launch
-    index.enable_timing(4)
+    # HIP events around EVERY scan launch of the timed region.  (Sampling every n-th launch is possible -- enable_timing(n) --
+    # and saves ~20 us of dispatch bubble per launch, but it biases the figure: a bracketed launch is dispatched a little
+    # later than its unbracketed neighbours, loses the race for CUs against the tail kernels of earlier steps, and
+    # measures ~3 % longer than the in-kernel stamps of the same launches.)
+    index.enable_timing(1)
     barrier()
     t0 = time.perf_counter()
     last = run_steps(args.steps, args.warmup)
