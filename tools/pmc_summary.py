@@ -7,7 +7,7 @@ def collect(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == counter and "scan_split_kernel" in r["Kernel_Name"] and ", true>" in r["Kernel_Name"]]
-    # ", true>" = the multi-pass form; the single-pass launches of the same template only warm the clocks
+    # ", true>" = the multi-pass form of the template (single-query callers get the ", false>" form)
     vals = vals[3:]          # drop the first launches
     return {"launches": len(vals), "mean_kb": sum(vals) / len(vals), "min_kb": min(vals), "max_kb": max(vals)}
 

@@ -12,11 +12,8 @@ for lo in range(0,N,125000):
     x=torch.randn((m,d),generator=g,device='cuda',dtype=torch.float32); x/=x.norm(dim=1,keepdim=True); ix.add_device(x)
 q=torch.randn((B,d),generator=g,device='cuda'); q/=q.norm(dim=1,keepdim=True)
 out=None
-# warm the clocks with SINGLE-PASS launches (their kernel has its own name, so they stay out of the profiled average)
-w=None
-for _ in range(250): w=ix.search_device(q[:ix.pass_queries],k,w)
-for _ in range(3): out=ix.search_device(q,k,out)
+for _ in range(5): out=ix.search_device(q,k,out)
 torch.cuda.synchronize()
 t0=time.perf_counter()
-for _ in range(40): ix.search_device(q,k,out)
-torch.cuda.synchronize(); print('sequential ms/launch %.4f (%d queries, %d passes)'%((time.perf_counter()-t0)/40*1e3,B,B//ix.pass_queries))
+for _ in range(30): ix.search_device(q,k,out)
+torch.cuda.synchronize(); print('sequential ms/launch %.4f (%d queries, %d passes)'%((time.perf_counter()-t0)/30*1e3,B,B//ix.pass_queries))
