@@ -106,7 +106,9 @@ def main():
     if args.check:
         nc = args.check
         op = ho.Postings(postings.n_docs, postings.n_terms, postings.offsets, postings.doc_ids, postings.impacts)
+        t_cpu = time.perf_counter()
         es, ei = ho.bm25_search(op, sparse_q[:nc], depth)
+        cpu_bm25_s = time.perf_counter() - t_cpu
         ok_sparse = bool(np.array_equal(sids[:nc].cpu().numpy(), ei) and np.array_equal(s32[:nc].cpu().numpy(), es))
         xs = []
         for c in range(0, N, 125000):
@@ -116,11 +118,16 @@ def main():
             x /= x.norm(dim=1, keepdim=True)
             xs.append(x.cpu().numpy())
         xh = np.concatenate(xs)
+        t_cpu = time.perf_counter()
         ds, di = ho.flat_search(xh, queries[:nc].cpu().numpy(), depth, ho.METRIC_IP)
+        cpu_dense_s = time.perf_counter() - t_cpu
         ok_dense = bool(np.array_equal(dids[:nc].cpu().numpy(), di))
         efs, efi = ho.rrf_fuse(di, ei, k)
         ok_fused = bool(np.array_equal(hids[:nc].cpu().numpy(), efi) and np.array_equal(hs[:nc].cpu().numpy(), efs))
-        ok = {"dense_ids": ok_dense, "bm25_ids_scores": ok_sparse, "fused_ids_scores": ok_fused, "queries_checked": nc}
+        ok = {"dense_ids": ok_dense, "bm25_ids_scores": ok_sparse, "fused_ids_scores": ok_fused, "queries_checked": nc,
+              # the oracle legs timed on this box's host cores while they produce the expected values (numpy, one process)
+              "cpu_oracle_qps": {"bm25_taat": round(nc / cpu_bm25_s, 2), "dense_fp64": round(nc / cpu_dense_s, 2),
+                                 "hybrid": round(nc / (cpu_bm25_s + cpu_dense_s), 2), "queries": nc}}
     bytes_sparse = (b1["bytes_algorithmic"] - b0["bytes_algorithmic"])
     print(json.dumps({
         "workload": f"configs[2]: {N} chunks, dense IP top-{depth} + BM25 TAAT top-{depth} + RRF -> top-{k}",
