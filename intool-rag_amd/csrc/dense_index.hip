@@ -49,6 +49,9 @@ constexpr int kExRows = 1024;      // rows per workgroup in the exhaustive path 
                                    // resident scan workgroup, or its launch would serialise behind the next scan)
 constexpr int kMaxK = 1000;
 constexpr int kSlackGroups = 6;
+// 64-query tiles: eps ~ |x| |q - bf16(q)| ~ 1.2e-3 |x||q| is ~25x wider, and the number of rows within eps of the k-th score
+// grows with k (1M unit vectors, d = 1024: ~2 at k = 10, ~8 at k = 50), so the slack does too
+__host__ __device__ constexpr int slack_groups64(int k) { return k > 16 ? k : 16; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -648,7 +651,7 @@ struct FinishArgs {
     u64* sel;                        // [nq, 64] selected groups (fast path)
     u64* cand_k;                     // [nq, 1024] re-scored candidates
     i64* cand_i;
-    double* qn2;                     // [nq]
+    double* qn2;                     // [nq][2]: exact |q|^2 and |q - bf16(q)|^2
     float* sec;                      // [nq, 64] `second` of every selected group (fin_rescore -> fin_final)
     const float* gmax2;              // the scan's second-value array, gstride floats per query
     int64_t gstride;
@@ -664,11 +667,17 @@ struct FinishArgs {
 // (1.97e-3 ~ 2^-9), and the quad tag in the two low mantissa bits (kTagSlack of the value's magnitude).
 constexpr double kTagSlack = 4.76837158203125e-07;  // 2^-21
 template <int METRIC>
-__device__ __forceinline__ double scan_eps(int dpad, int split, double qn2, double xn2)
+__device__ __forceinline__ double scan_eps(int dpad, int split, double qn2, double xn2, double dq2)
 {
     const double xn = sqrt(xn2), qn = sqrt(qn2);
     const double u = 5.9604644775390625e-08;  // 2^-24
-    double eps = (1.05 * (double)(dpad + (split ? 80 : 2)) * u + (split == 1 ? 1.52587890625e-05 : split == 2 ? 1.97e-03 : 0.0)) * qn * xn;
+    double eps = 1.05 * (double)(dpad + (split ? 80 : 2)) * u * qn * xn;
+    if (split == 1) eps += 1.52587890625e-05 * qn * xn;
+    // 64-query tiles: the scan sees q^ = bf16(q) and x^ = hi + lo.  |<x, q - q^>| <= |x| |q - q^| (Cauchy-Schwarz) with
+    // |q - q^| computed exactly per query (dq2, same RNE conversion as the scan prologue) -- about 0.3 * 2^-9 |q| for
+    // ordinary data instead of the element-wise worst case 2^-9 |q|, which is what lets K' = k + 12 certify;
+    // |<x - x^, q^>| <= 2^-17 |x| |q^| for the two-term split of the rows.
+    if (split == 2) eps += 7.62939453125e-06 * 1.01 * qn * xn + 1.0001 * sqrt(dq2) * xn;
     if (METRIC == HIPRAG_METRIC_IP) return eps + kTagSlack * (qn * xn + eps);
     eps = 2.0 * eps + 4.0 * u * (xn * xn + qn * xn) + 4.0 * u * qn2;  // 2 * acc - norm, and the rounding of |q|^2 - dist
     return eps + kTagSlack * (2.0 * qn * xn + xn * xn + eps);
@@ -713,26 +722,28 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
     KeyId* red = reinterpret_cast<KeyId*>(seli + K1);
     double* dred = reinterpret_cast<double*>(red + 2 * (kSelThreads / 64));
     u64& kth_key = *reinterpret_cast<u64*>(dred + kSelThreads / 64);  // all LDS in the one dynamic array
-    float* qv = reinterpret_cast<float*>(dred + kSelThreads / 64 + 1);
+    float* qv = reinterpret_cast<float*>(dred + 2 * (kSelThreads / 64) + 1);   // dred: |q|^2 parts, kth_key, |q - q^|^2 parts
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int dpad = a.P * 8;
 
     // query into LDS (zero padded) and its exact squared norm
-    double qpart = 0.0;
+    double qpart = 0.0, dpart = 0.0;
     for (int c = tid; c < dpad; c += kSelThreads) {
         float v = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
         qv[c] = v;
         qpart += (double)v * (double)v;
+        const double dv = (double)v - (double)(float)(__bf16)v;
+        dpart += dv * dv;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
-    if (lane == 0) dred[wave] = qpart;
+    for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
+    if (lane == 0) { dred[wave] = qpart; dred[kSelThreads / 64 + 1 + wave] = dpart; }
     if (tid == 0) kth_key = 0;
     __syncthreads();
-    double qn2 = 0.0;
-    for (int w = 0; w < kSelThreads / 64; ++w) qn2 += dred[w];
+    double qn2 = 0.0, dq2 = 0.0;
+    for (int w = 0; w < kSelThreads / 64; ++w) { qn2 += dred[w]; dq2 += dred[kSelThreads / 64 + 1 + w]; }
 
     {
         const u64* sk = a.ck + (int64_t)q * a.ncand;
@@ -775,7 +786,7 @@ __global__ __launch_bounds__(kSelThreads) void finish_kernel(FinishArgs a)
         if (bk != 0) {
             const float m = unord32((u32)(bk >> 32));
             if (m > -1.0e38f) {  // below that: padding only, every real row was re-scored
-                const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits));
+                const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits), dq2);
                 if (!(kth_on_scan_scale<METRIC>(kth_key, qn2) > (double)m + eps)) flag = 1;
             }
         }
@@ -803,7 +814,7 @@ template <int NPL, int NW>
 __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
 {
     __shared__ u64 lists[NW > 1 ? NW * 64 : 1];
-    __shared__ double dred[NW];
+    __shared__ double dred[2 * NW];
     constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -811,13 +822,15 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     const int K1 = a.Kp + 1;
     if (a.dbg && tid == 0) atomicMin(a.dbg + 1, (unsigned long long)wall_clock64());
 
-    double qpart = 0.0;
+    double qpart = 0.0, dpart = 0.0;
     for (int c = tid; c < a.d; c += NT) {
-        const double v = (double)a.q[(int64_t)q * a.d + c];
+        const float vf = a.q[(int64_t)q * a.d + c];
+        const double v = (double)vf, dv = v - (double)(float)(__bf16)vf;   // the scan's query tile holds bf16(q), RNE
         qpart += v * v;
+        dpart += dv * dv;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) qpart += __shfl_xor(qpart, off);
+    for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
     const u64* sk = a.ck + (int64_t)q * a.ncand;
     const i64* si = a.ci + (int64_t)q * a.ncand;
     u64 c[NPL];
@@ -834,10 +847,10 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     wave_topk_packed<NPL>(c, K1, L);
     if (NW == 1) {  // the usual case (<= 512 candidates): one wave, no LDS, runs beside a resident scan workgroup
         a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L.e : 0;
-        if (lane == 0) a.qn2[q] = qpart;
+        if (lane == 0) { a.qn2[2 * q] = qpart; a.qn2[2 * q + 1] = dpart; }
         return;
     }
-    if (lane == 0) dred[wave] = qpart;
+    if (lane == 0) { dred[wave] = qpart; dred[NW + wave] = dpart; }
     lists[wave * 64 + lane] = lane < K1 ? L.e : 0;
     __syncthreads();
     if (wave == 0) {
@@ -848,9 +861,10 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
         wave_topk_packed<NW>(c2, K1, L2);
         a.sel[(int64_t)q * 64 + lane] = lane < K1 ? L2.e : 0;
         if (lane == 0) {
-            double qn2 = 0.0;
-            for (int w = 0; w < NW; ++w) qn2 += dred[w];
-            a.qn2[q] = qn2;
+            double qn2 = 0.0, dq2 = 0.0;
+            for (int w = 0; w < NW; ++w) { qn2 += dred[w]; dq2 += dred[NW + w]; }
+            a.qn2[2 * q] = qn2;
+            a.qn2[2 * q + 1] = dq2;
         }
     }
 }
@@ -915,9 +929,9 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
     }
     const u64 e_l = a.sel[(int64_t)q * 64 + lane];                       // lanes 0..K' hold the selected groups
     const float m2_l = lane < a.Kp ? a.sec[(int64_t)q * 64 + lane] : -FLT_MAX;
-    const double qn2 = a.qn2[q];
+    const double qn2 = a.qn2[2 * q], dq2 = a.qn2[2 * q + 1];
     const int dpad = a.P * 8;
-    const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits));
+    const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(*a.max_norm2_bits), dq2);
 
     const u64 t0 = wave_kth_of_lanes(m, a.k);   // k lanes hold a key >= t0: nothing below t0 can reach the top k
     WaveListPair F;
@@ -1211,13 +1225,14 @@ struct DenseIndex {
     }
 
     int pass_queries() const { return scan_mode == 2 ? 64 : 32; }
-    // Operand mode of a launch for top-k: the 64-query tiles need K' = k + 22 re-scored groups, and the wave-list
-    // selectors hold 64 entries, so deeper k (the hybrid retriever's fusion depth 50) runs the 32-query split scan
-    // (K' = k + 6), which stays on the fast finish path up to k = 57.
-    int mode_for(int k) const { return (scan_mode == 2 && std::max(k + 22, 32) + 1 > 64) ? 1 : scan_mode; }
+    // Operand mode of a launch for top-k: the 64-query tiles re-score K' = k + max(16, k) groups (measured on 1M unit
+    // vectors: k + 12 certifies every query at k = 10 but only 99 % at k = 20; an uncertified query costs an exhaustive
+    // pass) and the wave-list selectors hold 64 entries, so k <= 31 runs on them; deeper k (the reference's retrieval
+    // depth is 50, page_retriever.py:92) uses the 32-query split scan (K' = k + 6, fast finish path up to k = 57).
+    int mode_for(int k) const { return (scan_mode == 2 && k + slack_groups64(k) + 1 > 64) ? 1 : scan_mode; }
     int pass_queries_for(int k) const { return mode_for(k) == 2 ? 64 : 32; }
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
-    int kprime(int k) const { return mode_for(k) == 2 ? std::max(k + 22, 32) : k + kSlackGroups; }
+    int kprime(int k) const { return mode_for(k) == 2 ? k + slack_groups64(k) : k + kSlackGroups; }
 
     // Workspace of one slot for (up to launch_q queries, k), allocated on first use: an unused slot costs nothing.
     int32_t reserve_slot(int slot, int k)
@@ -1240,8 +1255,8 @@ struct DenseIndex {
         if ((rc = w.ck.reserve(Q * nlists * K1 * sizeof(u64)))) return rc;
         if ((rc = w.ci.reserve(Q * nlists * K1 * sizeof(i64)))) return rc;
         if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
-        // sel[Q][64] u64 | cand_k[Q][256] u64 | cand_i[Q][256] i64 | qn2[Q] f64 | sec[Q][64] f32
-        if ((rc = w.fin.reserve(Q * (64 + 2 * kCandPerQuery + 1 + 32) * 8))) return rc;
+        // sel[Q][64] u64 | cand_k[Q][256] u64 | cand_i[Q][256] i64 | qn2[Q][2] f64 | sec[Q][64] f32
+        if ((rc = w.fin.reserve(Q * (64 + 2 * kCandPerQuery + 2 + 32) * 8))) return rc;
         if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
         w.k = kk;
@@ -1334,7 +1349,7 @@ struct DenseIndex {
             fa.cand_k = fin_base + (size_t)launch_q * 64;
             fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)launch_q * kCandPerQuery);
             fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)launch_q * kCandPerQuery);
-            fa.sec = reinterpret_cast<float*>(fa.qn2 + launch_q);
+            fa.sec = reinterpret_cast<float*>(fa.qn2 + 2 * (size_t)launch_q);
             fa.gmax2 = w.gmax.as<float>() + (size_t)launch_q * gstride;
             fa.gstride = gstride;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
@@ -1352,7 +1367,7 @@ struct DenseIndex {
                                (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
             fa.ncand = nchunks * K1;
             const size_t fin_lds = (size_t)kSelChunk * 16 + (size_t)K1 * 16 + 2 * (kSelThreads / 64) * sizeof(KeyId) +
-                                   (kSelThreads / 64 + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
+                                   (2 * (kSelThreads / 64) + 1) * sizeof(double) + (size_t)P * 8 * sizeof(float);
             auto fin = finish_kernel<METRIC>;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(fin), fin_lds); if (lrc) return lrc; }
             hipLaunchKernelGGL(fin, dim3(nq), dim3(kSelThreads), fin_lds, st, fa);

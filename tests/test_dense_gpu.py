@@ -255,8 +255,8 @@ def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
 
 
 def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
-    """k = 50 (the hybrid retriever's fusion depth) needs more re-scored groups than the 64-query tiles' selectors hold,
-    so those launches run the 32-query split scan; k = 10 on the same index keeps the 64-query tiles."""
+    """k = 30 still runs on the 64-query tiles (K' = 60 groups); k = 50 (the reference's retrieval depth) needs more
+    re-scored groups than their selectors hold, so those launches run the 32-query split scan."""
     from hiprag import HipFlatIndex
     n, d = 30000, 384
     x = ho.synthetic_vectors(n, d, seed=95)
@@ -266,10 +266,12 @@ def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
     p0 = ix.stats()["passes"]
     _check(ix, x, q, 50, ho.METRIC_IP)
     p1 = ix.stats()["passes"]
-    _check(ix, x, q, 10, ho.METRIC_IP)
+    _check(ix, x, q, 30, ho.METRIC_IP)
     p2 = ix.stats()["passes"]
-    assert (p1 - p0, p2 - p1) == (4, 2)          # 100 queries: 4 passes of 32, then 2 passes of 64
-    assert ix.stats()["fallback_queries"] == 0
+    _check(ix, x, q, 10, ho.METRIC_IP)
+    p3 = ix.stats()["passes"]
+    assert (p1 - p0, p2 - p1, p3 - p2) == (4, 2, 2)          # 100 queries: 4 passes of 32, then 2 passes of 64 twice
+    assert ix.stats()["fallback_queries"] <= 3             # the certificate may send a rare query down the exhaustive path
 
 
 def test_full_size_1m_x_1024_properties(gpu):
