@@ -105,13 +105,14 @@ int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle);
 typedef struct hipidx_stats {
     int64_t passes;            /* scan passes so far (one per <= pass_queries queries; several per launch) */
     int64_t queries;           /* queries answered */
-    int64_t fallback_queries;  /* queries whose fast-path certificate failed and took the exhaustive path */
+    int64_t fallback_queries;  /* queries that took the exhaustive path (certificate failed and round B overflowed) */
     int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
     int64_t timed_passes;      /* scan LAUNCHES averaged into avg_scan_ms (at most the last 512) */
     float avg_scan_ms;         /* mean HIP-event duration of the scan kernel since timing was enabled, else -1 */
     float avg_scan_wall_ms;    /* same launches on the GPU wall clock, stamped inside the kernel: first wave in -> last wave out */
     float avg_scan_gap_ms;     /* mean idle time between consecutive timed scans (last wave out -> next first wave in) */
     int64_t launches;          /* scan kernel launches so far (each runs 1..launch_queries/pass_queries passes back to back) */
+    int64_t roundb_queries;    /* queries whose first certificate failed and that the second finish round settled (cheap) */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
 /* on = n > 0: HIP events (on the launch stream) around every n-th scan launch, in-kernel wall-clock stamps on every launch;

@@ -52,6 +52,7 @@ constexpr int kSlackGroups = 6;
 // 64-query tiles: eps ~ |x| |q - bf16(q)| ~ 1.2e-3 |x||q| is ~25x wider, and the number of rows within eps of the k-th score
 // grows with k (1M unit vectors, d = 1024: ~2 at k = 10, ~8 at k = 50), so the slack does too
 __host__ __device__ constexpr int slack_groups64(int k) { return k > 16 ? k : 16; }
+constexpr int kMaxK64 = 57;   // deepest k on the 64-query tiles: K' is capped at 63 (wave lists), round B takes what that misses
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -658,6 +659,9 @@ struct FinishArgs {
     int d, P, k, Kp;           // Kp = K' groups re-scored; K1 = Kp + 1
     unsigned long long* dbg;   // HIPRAG_DEBUG_GAPS only: [8] wall-clock stamps of this launch's tail kernels
     int chunk;                 // blocks per flush of the scan that filled gmax
+    float* tau;                // [nq] round-B threshold of a flagged query: every row that can reach its top k sits in a group
+                               //      whose `first` is >= tau (second round of the finish, below)
+    int* rb_count;             // [nq] groups collected by round B (zeroed by fin_final)
     int split;                 // scan operand mode: 0 exact fp32, 1 bf16 hi/lo split, 2 split x + hi-only queries (64/pass)
 };
 
@@ -979,8 +983,136 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
         }
         a.flags[q] = flag;
         a.arrivals[q] = 0;
-        if (flag) atomicAdd(a.fallback_counter, 1ull);
+        a.rb_count[q] = 0;
+        if (flag) {
+            // tau = (k-th exact score among the rows seen so far) - eps, rounded DOWN to float: a row that beats that k-th
+            // score has scan value >= tau, so round B re-scores every group whose `first` reaches tau
+            const double t = kth_on_scan_scale<METRIC>(kth_key, qn2) - eps;
+            float tf = t > -3.0e38 ? (float)t : -FLT_MAX;
+            if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
+            a.tau[q] = tf;
+        }
         if (a.dbg) atomicMin(a.dbg + 4, ~(unsigned long long)wall_clock64());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Round B of the finish: a query whose certificate failed (more than K' groups within eps of its k-th score -- half of
+// the queries at k = 50 on the 64-query tiles, where K' is capped at 63 by the wave lists) is NOT sent to the exhaustive
+// path straight away.  fin_final left tau = (k-th exact score so far) - eps; every row that can still enter the top k
+// has a scan value >= tau, so it suffices to re-score the groups whose `first` reaches tau:
+//   roundb_collect_kernel   flagged queries only: compact those group slots (atomic append, cap kRoundBGroups)
+//   roundb_rescore_kernel   all 16 rows of every collected group in fp64
+//   roundb_final_kernel     exact top-k of the <= 4096 rows under (score, id); clears the flag
+// Costs one more read of the query's N/16 group values and ~1 MB of rows -- microseconds, against a full fp64 pass over
+// the index for the exhaustive path, which now only sees queries with more than kRoundBGroups such groups (ties).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRoundBGroups = 256;
+
+struct RoundBArgs {
+    const float4* xb;
+    const float* q;
+    const float* gmax;         // `first` values, gstride per query
+    int64_t gstride, ngroups;
+    int* flags;
+    const float* tau;
+    int* count;                // [nq]
+    u32* slots;                // [nq][kRoundBGroups]
+    u64* bk;                   // [nq][kRoundBGroups * 16]
+    i64* bi;
+    double* out64;
+    float* out32;
+    int64_t* out_ids;
+    unsigned long long* fallback_counter;   // queries that go on to the exhaustive path
+    unsigned long long* roundb_counter;     // queries settled by round B
+    int64_t ntotal, id_base, bpw, nblocks;
+    int d, P, k, chunk;
+};
+
+// grid (ceil(ngroups / 4096), nq), 256 threads, 16 values per thread
+__global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
+{
+    const int q = blockIdx.y;
+    if (!a.flags[q]) return;
+    const float tau = a.tau[q];
+    const float* src = a.gmax + (int64_t)q * a.gstride;
+    const int64_t base = (int64_t)blockIdx.x * 4096 + threadIdx.x * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t i = base + it * 1024;
+        float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (i + 3 < a.ngroups) {
+            const float4 x = *reinterpret_cast<const float4*>(src + i);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+            for (int t = 0; t < 4; ++t)
+                if (i + t < a.ngroups) v[t] = src[i + t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (v[t] >= tau && v[t] > -1.0e38f) {
+                const int pos = atomicAdd(a.count + q, 1);
+                if (pos < kRoundBGroups) a.slots[(int64_t)q * kRoundBGroups + pos] = (u32)(i + t);
+            }
+    }
+}
+
+// grid (32, nq), 256 threads: wave g re-scores quad g of collected groups j = blockIdx.x, blockIdx.x + 32, ...
+template <int METRIC>
+__global__ __launch_bounds__(256) void roundb_rescore_kernel(RoundBArgs a)
+{
+    extern __shared__ float qv[];
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int q = blockIdx.y;
+    if (!a.flags[q]) return;
+    const int n = a.count[q];
+    if (n > kRoundBGroups || (int)blockIdx.x >= n) return;
+    const int dpad = a.P * 8;
+    for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+    __syncthreads();
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        int64_t blk;
+        int gh;
+        group_decode((i64)a.slots[(int64_t)q * kRoundBGroups + j], a.bpw, a.nblocks, a.chunk, blk, gh);
+        const int r0 = 8 * g + 4 * gh;
+        const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+        const i64 row = blk * kRowsPerBlock + r0 + (lane & 3);
+        if (lane < 4) {
+            const int64_t o = ((int64_t)q * kRoundBGroups + j) * 16 + g * 4 + lane;
+            a.bk[o] = row < a.ntotal ? ord64(METRIC == HIPRAG_METRIC_IP ? s : -s) : 0ull;
+            a.bi[o] = row;
+        }
+    }
+}
+
+// one wave per query
+template <int METRIC>
+__global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (!a.flags[q]) return;
+    const int n = a.count[q];
+    if (n > kRoundBGroups) {   // too many groups within eps (massive ties): the exhaustive path settles it
+        if (lane == 0) atomicAdd(a.fallback_counter, 1ull);
+        return;
+    }
+    const int ncand = n * 16;
+    const u64* ck = a.bk + (int64_t)q * kRoundBGroups * 16;
+    const i64* ci = a.bi + (int64_t)q * kRoundBGroups * 16;
+    u64 m = 0;
+    for (int i = lane; i < ncand; i += 64) { const u64 kk = ck[i]; m = kk > m ? kk : m; }
+    const u64 t0 = wave_kth_of_lanes(m, a.k);
+    WaveListPair F;
+    F.init();
+    for (int i0 = 0; i0 < ncand; i0 += 64) {
+        const int i = i0 + lane;
+        const u64 kk = i < ncand ? ck[i] : 0ull;
+        F.offer(kk >= t0 ? kk : 0ull, i < ncand ? ci[i] : -1, a.k);
+    }
+    if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
+    if (lane == 0) {
+        a.flags[q] = 0;
+        atomicAdd(a.roundb_counter, 1ull);
     }
 }
 
@@ -1114,7 +1246,7 @@ struct DenseIndex {
     int scan_mode = 2;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo, 32 q/pass), q64 = 2 (default)
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin; int split = 0, chunk = kChunk; int k = 0; int64_t blocks = 0; int ev_idx = -1; };
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin, rb; int split = 0, chunk = kChunk; int k = 0; int64_t blocks = 0; int ev_idx = -1; };
     static constexpr int kSlots = 8;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
@@ -1136,6 +1268,7 @@ struct DenseIndex {
     int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
     unsigned* max_norm2_bits() { return scalars.as<unsigned>(); }
     unsigned long long* fallback_counter() { return reinterpret_cast<unsigned long long*>(scalars.as<unsigned>() + 2); }
+    unsigned long long* roundb_counter() { return reinterpret_cast<unsigned long long*>(scalars.as<unsigned>() + 4); }
 
     ~DenseIndex()
     {
@@ -1225,14 +1358,14 @@ struct DenseIndex {
     }
 
     int pass_queries() const { return scan_mode == 2 ? 64 : 32; }
-    // Operand mode of a launch for top-k: the 64-query tiles re-score K' = k + max(16, k) groups (measured on 1M unit
-    // vectors: k + 12 certifies every query at k = 10 but only 99 % at k = 20; an uncertified query costs an exhaustive
-    // pass) and the wave-list selectors hold 64 entries, so k <= 31 runs on them; deeper k (the reference's retrieval
-    // depth is 50, page_retriever.py:92) uses the 32-query split scan (K' = k + 6, fast finish path up to k = 57).
-    int mode_for(int k) const { return (scan_mode == 2 && k + slack_groups64(k) + 1 > 64) ? 1 : scan_mode; }
+    // Operand mode of a launch for top-k: the 64-query tiles re-score K' = min(63, k + max(16, k)) groups (measured on 1M
+    // unit vectors: k + 12 certifies every query at k = 10 but only 99 % at k = 20; the 64-entry wave lists cap K' at 63,
+    // where about half of the k = 50 queries -- the reference's retrieval depth, page_retriever.py:92 -- fail the
+    // certificate and are settled by round B of the finish instead).  k > 57 uses the 32-query split scan.
+    int mode_for(int k) const { return (scan_mode == 2 && k > kMaxK64) ? 1 : scan_mode; }
     int pass_queries_for(int k) const { return mode_for(k) == 2 ? 64 : 32; }
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
-    int kprime(int k) const { return mode_for(k) == 2 ? k + slack_groups64(k) : k + kSlackGroups; }
+    int kprime(int k) const { return mode_for(k) == 2 ? std::min(63, k + slack_groups64(k)) : k + kSlackGroups; }
 
     // Workspace of one slot for (up to launch_q queries, k), allocated on first use: an unused slot costs nothing.
     int32_t reserve_slot(int slot, int k)
@@ -1257,6 +1390,8 @@ struct DenseIndex {
         if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
         // sel[Q][64] u64 | cand_k[Q][256] u64 | cand_i[Q][256] i64 | qn2[Q][2] f64 | sec[Q][64] f32
         if ((rc = w.fin.reserve(Q * (64 + 2 * kCandPerQuery + 2 + 32) * 8))) return rc;
+        // round B: tau[Q] f32 | count[Q] i32 | slots[Q][256] u32 | keys[Q][4096] u64 | ids[Q][4096] i64
+        if ((rc = w.rb.reserve(Q * (8 + kRoundBGroups * 4 + (size_t)kRoundBGroups * 16 * 16)))) return rc;
         if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
         w.k = kk;
@@ -1352,6 +1487,12 @@ struct DenseIndex {
             fa.sec = reinterpret_cast<float*>(fa.qn2 + 2 * (size_t)launch_q);
             fa.gmax2 = w.gmax.as<float>() + (size_t)launch_q * gstride;
             fa.gstride = gstride;
+            float* rb_tau = w.rb.as<float>();
+            int* rb_count = reinterpret_cast<int*>(rb_tau + launch_q);
+            u32* rb_slots = reinterpret_cast<u32*>(rb_count + launch_q);
+            u64* rb_k = reinterpret_cast<u64*>(rb_slots + (size_t)launch_q * kRoundBGroups);
+            i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)launch_q * kRoundBGroups * 16);
+            fa.tau = rb_tau; fa.rb_count = rb_count;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 256) hipLaunchKernelGGL((fin_merge_kernel<4, 1>), dim3(nq), dim3(64), 0, st, fa);
@@ -1360,6 +1501,15 @@ struct DenseIndex {
             else hipLaunchKernelGGL((fin_merge_kernel<16, 16>), dim3(nq), dim3(1024), 0, st, fa);
             hipLaunchKernelGGL(fin_rescore_kernel<METRIC>, dim3((Kp + 3) / 4, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, fa);
             hipLaunchKernelGGL(fin_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, fa);
+            RoundBArgs rb;
+            rb.xb = fa.xb; rb.q = q_dev; rb.gmax = w.gmax.as<float>(); rb.gstride = gstride; rb.ngroups = ngroups;
+            rb.flags = flags; rb.tau = rb_tau; rb.count = rb_count; rb.slots = rb_slots; rb.bk = rb_k; rb.bi = rb_i;
+            rb.out64 = o64p; rb.out32 = o32p; rb.out_ids = oidp; rb.fallback_counter = fallback_counter();
+            rb.roundb_counter = roundb_counter(); rb.ntotal = ntotal; rb.id_base = id_base; rb.bpw = fa.bpw; rb.nblocks = nb;
+            rb.d = d; rb.P = P; rb.k = k; rb.chunk = w.chunk;
+            hipLaunchKernelGGL(roundb_collect_kernel, dim3((unsigned)std::max<int64_t>(1, (ngroups + 4095) / 4096), nq), dim3(256), 0, st, rb);
+            hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(32, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
+            hipLaunchKernelGGL(roundb_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, rb);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
             hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(kMaxQ), 0, st, flags, arrivals, fallback_counter(), nq);
         } else {
@@ -1732,6 +1882,11 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
     out->launches = ix->launches;
     out->queries = ix->queries;
     out->fallback_queries = (int64_t)fb;
+    {
+        unsigned long long rbq = 0;
+        HR_CHECK_HIP(hipMemcpy(&rbq, ix->roundb_counter(), sizeof(rbq), hipMemcpyDeviceToHost));
+        out->roundb_queries = (int64_t)rbq;
+    }
     out->bytes_per_pass = ix->nblocks() * ix->P * 1024 +
                           (ix->metric == HIPRAG_METRIC_L2 ? ix->nblocks() * kRowsPerBlock * 4 : 0);
     out->avg_scan_ms = -1.f;

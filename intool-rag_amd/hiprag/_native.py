@@ -26,7 +26,7 @@ class HipRagError(RuntimeError):
 class HipIdxStats(ctypes.Structure):
     _fields_ = [("passes", c_int64), ("queries", c_int64), ("fallback_queries", c_int64),
                 ("bytes_per_pass", c_int64), ("timed_passes", c_int64), ("avg_scan_ms", c_float),
-                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float), ("launches", c_int64)]
+                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float), ("launches", c_int64), ("roundb_queries", c_int64)]
 
 
 class HipBm25Stats(ctypes.Structure):

@@ -82,7 +82,8 @@ def test_zero_query_is_all_ties_lowest_ids_win(gpu, metric):
     s, i = _check(ix, x, q, 10, metric)
     if metric == ho.METRIC_IP:
         assert list(i[0]) == list(range(10))
-        assert ix.stats()["fallback_queries"] >= 1     # certificate must have refused the fast path
+        st = ix.stats()                                 # the certificate must have refused the first round: all 188 groups tie,
+        assert st["roundb_queries"] + st["fallback_queries"] >= 1   # round B re-scores them all
 
 
 @pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
@@ -234,7 +235,8 @@ def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mo
     ix.add(x)
     _check(ix, x, q, k, metric)
     _check(ix, x, q[:1], 50, metric)
-    assert ix.stats()["fallback_queries"] >= 1          # the zero query (and maybe the duplicate one) took the exhaustive path
+    st = ix.stats()                                      # the zero query ties all 438 groups: more than round B collects,
+    assert st["fallback_queries"] >= 1                   # so it took the exhaustive path
 
 
 @pytest.mark.parametrize("mode", ["split", "q64"])
@@ -255,8 +257,9 @@ def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
 
 
 def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
-    """k = 30 still runs on the 64-query tiles (K' = 60 groups); k = 50 (the reference's retrieval depth) needs more
-    re-scored groups than their selectors hold, so those launches run the 32-query split scan."""
+    """k = 50 (the reference's retrieval depth) runs on the 64-query tiles with K' capped at 63 groups: queries whose first
+    certificate fails are settled by round B of the finish, not by the exhaustive path.  k = 60 is past what the wave
+    lists hold, so those launches run the 32-query split scan."""
     from hiprag import HipFlatIndex
     n, d = 30000, 384
     x = ho.synthetic_vectors(n, d, seed=95)
@@ -264,14 +267,36 @@ def test_deep_k_switches_to_the_split_operands_and_stays_exact(gpu):
     ix = HipFlatIndex(d, ho.METRIC_IP)
     ix.add(x)
     p0 = ix.stats()["passes"]
-    _check(ix, x, q, 50, ho.METRIC_IP)
+    _check(ix, x, q, 60, ho.METRIC_IP)
     p1 = ix.stats()["passes"]
-    _check(ix, x, q, 30, ho.METRIC_IP)
+    _check(ix, x, q, 50, ho.METRIC_IP)
     p2 = ix.stats()["passes"]
     _check(ix, x, q, 10, ho.METRIC_IP)
     p3 = ix.stats()["passes"]
-    assert (p1 - p0, p2 - p1, p3 - p2) == (4, 2, 2)          # 100 queries: 4 passes of 32, then 2 passes of 64 twice
-    assert ix.stats()["fallback_queries"] <= 3             # the certificate may send a rare query down the exhaustive path
+    assert (p1 - p0, p2 - p1, p3 - p2) == (4, 2, 2)              # 100 queries: 4 passes of 32, then 2 passes of 64 twice
+    assert ix.stats()["fallback_queries"] <= 3                   # a query the first round cannot certify goes to round B
+
+
+def test_round_b_with_l2_metric_ties_and_overflow(gpu):
+    """Round B on both scales: 120 exact copies of one row, each in a group of its own, tie for the top 50 of the query
+    that equals them -- more tied groups than the first round re-scores (63), fewer than round B collects (256) -- so
+    that query is settled by round B, lowest ids first.  A zero query ties EVERY group: round B overflows and the
+    exhaustive path answers.  Results exact throughout."""
+    from hiprag import HipFlatIndex
+    n, d, k = 50000, 256, 50
+    x = ho.synthetic_vectors(n, d, seed=97)
+    copies = 1000 + 37 * np.arange(120)
+    x[copies] = x[7]
+    q = ho.synthetic_queries(70, d, seed=98)
+    q[1] = x[7]
+    q[2] = 0
+    for metric in (ho.METRIC_L2, ho.METRIC_IP):
+        ix = HipFlatIndex(d, metric)
+        ix.add(x)
+        s, i = _check(ix, x, q, k, metric)
+        assert list(i[1]) == [7] + list(copies[:49])
+        st = ix.stats()
+        assert st["roundb_queries"] >= 1 and st["fallback_queries"] >= 1
 
 
 def test_full_size_1m_x_1024_properties(gpu):
