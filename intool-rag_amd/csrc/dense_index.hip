@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
     }
 }
 
-// grid (32, nq), 256 threads: wave g re-scores quad g of collected groups j = blockIdx.x, blockIdx.x + 32, ...
+// grid (8, nq), 256 threads: wave g re-scores quad g of collected groups j = blockIdx.x, blockIdx.x + 8, ...
 template <int METRIC>
 __global__ __launch_bounds__(256) void roundb_rescore_kernel(RoundBArgs a)
 {
@@ -1508,7 +1508,7 @@ struct DenseIndex {
             rb.roundb_counter = roundb_counter(); rb.ntotal = ntotal; rb.id_base = id_base; rb.bpw = fa.bpw; rb.nblocks = nb;
             rb.d = d; rb.P = P; rb.k = k; rb.chunk = w.chunk;
             hipLaunchKernelGGL(roundb_collect_kernel, dim3((unsigned)std::max<int64_t>(1, (ngroups + 4095) / 4096), nq), dim3(256), 0, st, rb);
-            hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(32, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
+            hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(8, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
             hipLaunchKernelGGL(roundb_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, rb);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
             hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(kMaxQ), 0, st, flags, arrivals, fallback_counter(), nq);
