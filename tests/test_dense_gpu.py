@@ -382,3 +382,36 @@ def test_spare_cus_change_the_partition_not_the_results(gpu):
         _check(ix, x, q, 10, ho.METRIC_IP)
     with pytest.raises(Exception):
         ix.set_spare_cus(100000)
+
+
+def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
+    """Forty seeded random configurations -- rows, width, k, batch size, metric, operand mode, spare CUs, duplicated and
+    zero rows, un-normalised data -- through search(), every one compared id for id with the fp64 oracle."""
+    from hiprag import HipFlatIndex
+    rng = np.random.default_rng(20260101)
+    for case in range(40):
+        n = int(rng.choice([1, 31, 33, 500, 4097, 9000, 30011]))
+        d = int(rng.choice([8, 100, 128, 384, 1000, 1024]))
+        k = int(rng.choice([1, 5, 10, 31, 50, 57, 58, 64]))
+        nq = int(rng.choice([1, 2, 63, 64, 65, 200, 300]))
+        metric = [ho.METRIC_IP, ho.METRIC_L2][case % 2]
+        mode = ["q64", "q64", "split", "f32"][int(rng.integers(4))]
+        monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
+        x = ho.synthetic_vectors(n, d, seed=1000 + case)
+        q = ho.synthetic_queries(nq, d, seed=2000 + case)
+        if case % 3 == 0:
+            x *= rng.uniform(0.1, 30.0, size=(n, 1)).astype(np.float32)       # un-normalised rows
+        if case % 4 == 1 and n > 40:
+            x[rng.integers(0, n, size=20)] = x[3]                              # duplicates -> exact ties
+        if case % 5 == 2:
+            x[n // 2] = 0
+            q[0] = 0                                                           # zero row / zero query
+        ix = HipFlatIndex(d, metric)
+        ix.add(x[: n // 2])
+        ix.add(x[n // 2:])
+        if case % 6 == 3:
+            ix.set_spare_cus(int(rng.choice([1, 8, 100])))
+        try:
+            _check(ix, x, q, k, metric)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n={n} d={d} k={k} nq={nq} metric={metric} mode={mode}: {e}")
