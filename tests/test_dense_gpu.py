@@ -415,3 +415,41 @@ def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
             _check(ix, x, q, k, metric)
         except AssertionError as e:
             raise AssertionError(f"case {case}: n={n} d={d} k={k} nq={nq} metric={metric} mode={mode}: {e}")
+
+
+@pytest.mark.parametrize("streams", ["main", "side"])
+def test_deep_pipeline_with_changing_batch_shapes(gpu, monkeypatch, streams):
+    """Six launches in flight over the eight workspace slots, batch size and k changing from launch to launch (every slot's
+    buffers are re-shaped while older launches are still running), in both stream arrangements of the scans."""
+    import torch
+    from collections import deque
+    from hiprag import HipFlatIndex
+    from hiprag.sharded import ShardedFlatIndex
+    if streams == "side":
+        monkeypatch.setenv("HIPRAG_SCAN_STREAMS", "side")
+    n, d = 20000, 256
+    x = ho.synthetic_vectors(n, d, seed=71)
+    q = ho.synthetic_queries(256, d, seed=72)
+    ix = HipFlatIndex(d, "ip")
+    ix.add(x)
+    sh = ShardedFlatIndex(ix, 0)
+    qd = torch.from_numpy(q).cuda()
+    rng = np.random.default_rng(5)
+    plan = [(int(rng.choice([1, 17, 64, 65, 200, 256])), int(rng.choice([1, 10, 50]))) for _ in range(40)]
+    pending, got = deque(), []
+    for nq, k in plan:
+        pending.append((nq, k, sh.search_begin(qd[:nq], k)))
+        if len(pending) >= 6:
+            a, b, t = pending.popleft()
+            got.append((a, b, tuple(v.clone() for v in sh.search_end(t))))
+    while pending:
+        a, b, t = pending.popleft()
+        got.append((a, b, tuple(v.clone() for v in sh.search_end(t))))
+    torch.cuda.synchronize()
+    expect = {}
+    for nq, k, (s64, s32, ids) in got:
+        if (nq, k) not in expect:
+            expect[(nq, k)] = ho.flat_search(x, q[:nq], k, ho.METRIC_IP)
+        es, ei = expect[(nq, k)]
+        assert np.array_equal(ids.cpu().numpy(), ei), (nq, k)
+        assert np.allclose(s32.cpu().numpy(), es, rtol=0, atol=TOL)
