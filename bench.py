@@ -111,7 +111,9 @@ def main():
     queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
     queries /= queries.norm(dim=1, keepdim=True)
     # one scan LAUNCH per step: 256 queries = 4 passes of 64 run back to back inside the launch (each pass streams the
-    # local rows once for its own query tile); HIPRAG_LAUNCH_QUERIES / HIPRAG_SCAN_MODE change the split
+    # local rows once for its own query tile).  The library sizes a launch by the LOCAL row count so that it lasts about
+    # as long whatever the shard: 4 passes at 1M rows, 8 at 500k, 16 (1024 queries) at <= 250k rows per GPU.
+    # HIPRAG_LAUNCH_QUERIES / HIPRAG_SCAN_MODE change the split
     BATCH = index.launch_queries
     PASSES = (BATCH + index.pass_queries - 1) // index.pass_queries
     nb = N_QUERIES // BATCH

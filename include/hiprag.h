@@ -79,9 +79,11 @@ int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k,
  * tiles), 32 with HIPRAG_SCAN_MODE=split (hi/lo on both sides) or =f32 (exact fp32 MFMA).  All modes return the same
  * exact results; they differ in how wide the certificate's error bound is and how many rows get re-scored. */
 int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n);
-/* Queries one scan LAUNCH takes (default 256, HIPRAG_LAUNCH_QUERIES; a multiple of the pass size): the scan kernel runs
- * launch/pass passes back to back inside one launch -- each pass streams the index once for its own query tile -- so
- * that no kernel boundary (35-45 us of idle GPU) separates them.  The exact-fp32 mode runs one pass per launch. */
+/* Queries one scan LAUNCH takes (a multiple of the pass size): the scan kernel runs launch/pass passes back to back
+ * inside one launch -- each pass streams the index once for its own query tile -- so that no kernel boundary (45-60 us
+ * of idle GPU) separates them.  Sized by the index so that a launch lasts about 2.6 ms: 4 passes (256 queries) at
+ * 1M x 1024, 8 at half that, 16 (the cap, 1024 queries) from a quarter down; it changes when rows are added.
+ * HIPRAG_LAUNCH_QUERIES fixes it.  The exact-fp32 mode runs one pass per launch. */
 int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
 /* Two-phase form of one launch (nq <= hipidx_launch_queries) for callers that pipeline: begin = index scan into
  * workspace `slot` (0..7, allocated on first use); finish = group selection, fp64 re-score, top-k, certificate /

@@ -41,7 +41,7 @@ constexpr int kRowsPerBlock = 32;
 constexpr int kPieceFloats = 256;
 constexpr int kPieceVec4 = 64;
 // a PASS = the queries that share one read of the index: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
-constexpr int kMaxQ = 256;         // queries per LAUNCH: the split scans run up to kMaxQ / pass queries passes back to back
+constexpr int kMaxQ = 1024;        // most queries per LAUNCH (16 passes of 64): see DenseIndex::update_launch_q
 constexpr int kMaxDPad = 1024;    // d_pad limit (the 128 KiB query tile of the scan)
 constexpr int kSelChunk = kTile;   // entries per select tile (topk_device.h)
 constexpr int kSelThreads = 256;
@@ -1246,11 +1246,12 @@ struct DenseIndex {
     int scan_mode = 2;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo, 32 q/pass), q64 = 2 (default)
     DevBuf xb, norms, scalars;  // scalars: [0] max_norm2 bits (u32), [2..3] fallback counter (u64)
     // search workspace
-    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin, rb; int split = 0, chunk = kChunk; int k = 0; int64_t blocks = 0; int ev_idx = -1; };
+    struct Workspace { DevBuf gmax, qf, ck, ci, flags, ek, ei, fin, rb; int split = 0, chunk = kChunk; int k = 0, q = 0; int64_t blocks = 0; int ev_idx = -1; };
     static constexpr int kSlots = 8;   // passes in flight: the scan of pass i+1 runs beside the tails of passes i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
-    int launch_q = kMaxQ;     // HIPRAG_LAUNCH_QUERIES: queries one begin/finish pair takes (a multiple of the pass size)
+    int launch_q = 256;       // queries one begin/finish pair takes (a multiple of the pass size): update_launch_q
+    int launch_env = 0;       // HIPRAG_LAUNCH_QUERIES (0 = size launches by the index)
     // stats
     int64_t passes = 0, queries = 0, launches = 0;
     // timing: a ring of event pairs around the scan kernel, averaged by get_stats (no sync inside the search path)
@@ -1286,9 +1287,8 @@ struct DenseIndex {
         const char* ms = getenv("HIPRAG_SCAN_MODE");
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : 2;
         const char* lq = getenv("HIPRAG_LAUNCH_QUERIES");
-        launch_q = lq ? atoi(lq) : kMaxQ;
-        launch_q = std::max(pass_queries(), std::min(kMaxQ, launch_q / pass_queries() * pass_queries()));
-        if (scan_mode == 0) launch_q = pass_queries();   // the exact-fp32 scan (verification mode) runs one pass per launch
+        launch_env = lq ? atoi(lq) : 0;
+        update_launch_q();
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
@@ -1335,6 +1335,7 @@ struct DenseIndex {
                            norms.as<float>(), max_norm2_bits());
         HR_CHECK_HIP(hipGetLastError());
         ntotal += n;
+        update_launch_q();
         return HIPRAG_OK;
     }
 
@@ -1367,12 +1368,26 @@ struct DenseIndex {
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
     int kprime(int k) const { return mode_for(k) == 2 ? std::min(63, k + slack_groups64(k)) : k + kSlackGroups; }
 
+    // Passes per launch.  A launch chained behind its predecessor pays ~45-60 us of dispatch bubble and the tails of a
+    // launch are a fixed cost too, so launches are sized to last about as long as four passes over a 1M x 1024 index
+    // (2.6 ms) whatever the index size: 4 passes there, 8 at half a million rows, 16 (the cap) at an 8-way shard of it --
+    // where a 4-pass launch would spend a quarter of its time outside the scan.  HIPRAG_LAUNCH_QUERIES fixes the size.
+    void update_launch_q()
+    {
+        const int pq = pass_queries();
+        if (scan_mode == 0) { launch_q = pq; return; }   // the exact-fp32 scan (verification mode) runs one pass per launch
+        if (launch_env > 0) { launch_q = std::max(pq, std::min(kMaxQ, launch_env / pq * pq)); return; }
+        const double pass_bytes = (double)std::max<int64_t>(nblocks(), 1) * P * 1024.0;
+        const int passes = (int)std::lround(4.0 * 4.096e9 / pass_bytes);
+        launch_q = std::max(4, std::min(16, passes)) * pq;
+    }
+
     // Workspace of one slot for (up to launch_q queries, k), allocated on first use: an unused slot costs nothing.
     int32_t reserve_slot(int slot, int k)
     {
         Workspace& w = ws[slot];
         const int64_t nb = std::max<int64_t>(nblocks(), 1);
-        if (k <= w.k && nb <= w.blocks) return HIPRAG_OK;
+        if (k <= w.k && nb <= w.blocks && launch_q <= w.q) return HIPRAG_OK;
         const int kk = std::max(k, w.k);
         const int64_t nbb = std::max(nb, w.blocks);
         const int64_t gstride = ((2 * nbb + 3) / 4) * 4;
@@ -1381,7 +1396,7 @@ struct DenseIndex {
         const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
         const int ekk = std::min(kk, kExRows);
         const int64_t nlists = std::max(nchunks, ((gstride + kSelPerWave - 1) / kSelPerWave + 3) / 4 * 4);
-        const size_t Q = (size_t)launch_q;
+        const size_t Q = (size_t)std::max(launch_q, w.q);
         int32_t rc;
         if ((rc = w.gmax.reserve(2 * Q * gstride * sizeof(float)))) return rc;  // first | second
         if ((rc = w.qf.reserve((size_t)P * kPieceVec4 * sizeof(float4)))) return rc;
@@ -1396,6 +1411,7 @@ struct DenseIndex {
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
         w.k = kk;
         w.blocks = nbb;
+        w.q = (int)Q;
         return HIPRAG_OK;
     }
 
@@ -1408,7 +1424,7 @@ struct DenseIndex {
         const int64_t nb = nblocks();
         ScanArgs sa;
         sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>();
-        sa.gmax2 = sa.gmax + (size_t)launch_q * (((2 * w.blocks + 3) / 4) * 4);
+        sa.gmax2 = sa.gmax + (size_t)w.q * (((2 * w.blocks + 3) / 4) * 4);
         sa.gstride = ((2 * w.blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = mode != 0;
@@ -1461,7 +1477,7 @@ struct DenseIndex {
         const int Kp = kprime(k), K1 = Kp + 1;
         const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
         int* flags = w.flags.as<int>();
-        int* arrivals = flags + launch_q;
+        int* arrivals = flags + w.q;
 
         FinishArgs fa;
         fa.xb = xb.as<float4>(); fa.q = q_dev; fa.ck = w.ck.as<u64>(); fa.ci = w.ci.as<i64>();
@@ -1481,17 +1497,17 @@ struct DenseIndex {
             fa.ncand = wave_cand;
             u64* fin_base = w.fin.as<u64>();
             fa.sel = fin_base;
-            fa.cand_k = fin_base + (size_t)launch_q * 64;
-            fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)launch_q * kCandPerQuery);
-            fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)launch_q * kCandPerQuery);
-            fa.sec = reinterpret_cast<float*>(fa.qn2 + 2 * (size_t)launch_q);
-            fa.gmax2 = w.gmax.as<float>() + (size_t)launch_q * gstride;
+            fa.cand_k = fin_base + (size_t)w.q * 64;
+            fa.cand_i = reinterpret_cast<i64*>(fa.cand_k + (size_t)w.q * kCandPerQuery);
+            fa.qn2 = reinterpret_cast<double*>(fa.cand_i + (size_t)w.q * kCandPerQuery);
+            fa.sec = reinterpret_cast<float*>(fa.qn2 + 2 * (size_t)w.q);
+            fa.gmax2 = w.gmax.as<float>() + (size_t)w.q * gstride;
             fa.gstride = gstride;
             float* rb_tau = w.rb.as<float>();
-            int* rb_count = reinterpret_cast<int*>(rb_tau + launch_q);
-            u32* rb_slots = reinterpret_cast<u32*>(rb_count + launch_q);
-            u64* rb_k = reinterpret_cast<u64*>(rb_slots + (size_t)launch_q * kRoundBGroups);
-            i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)launch_q * kRoundBGroups * 16);
+            int* rb_count = reinterpret_cast<int*>(rb_tau + w.q);
+            u32* rb_slots = reinterpret_cast<u32*>(rb_count + w.q);
+            u64* rb_k = reinterpret_cast<u64*>(rb_slots + (size_t)w.q * kRoundBGroups);
+            i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)w.q * kRoundBGroups * 16);
             fa.tau = rb_tau; fa.rb_count = rb_count;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);

@@ -56,7 +56,6 @@ class ShardedFlatIndex:
             # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
             # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
             local.set_spare_cus(8)
-        self.max_pass = local.launch_queries    # queries per search_begin (see hipidx_launch_queries)
         # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
         # the tail of batch i+1, which cannot start before scan i+1 ends
         self.side = [torch.cuda.Stream(device=local.device) for _ in range(N_SLOTS)]
@@ -66,6 +65,12 @@ class ShardedFlatIndex:
         self._slot_ended = [False] * N_SLOTS
         self._bufs = [dict() for _ in range(N_SLOTS)]
         self._scan_done = [torch.cuda.Event() for _ in range(N_SLOTS)]
+
+    @property
+    def max_pass(self) -> int:
+        """Queries one search_begin takes = hipidx_launch_queries of the local index (it is sized by the shard: more
+        passes per launch on a smaller shard, so a launch lasts about as long whatever the shard size)."""
+        return self.local.launch_queries
 
     def _buffers(self, slot: int, nq: int, k: int, dev):
         """Per-slot result buffers and events, created once per (nq, k): the steady state allocates nothing."""
