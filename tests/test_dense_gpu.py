@@ -217,7 +217,7 @@ def test_two_stream_pipeline_matches_oracle(gpu):
     assert np.array_equal(idsb.cpu().numpy(), ei)
 
 
-@pytest.mark.parametrize("mode", ["f32", "split", "q64"])
+@pytest.mark.parametrize("mode", ["f32", "split", "q64", "bf16"])
 @pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
 def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mode, metric):
     """HIPRAG_SCAN_MODE picks how candidates are generated (exact fp32 MFMA / bf16 hi-lo split / 64-query hi-only query
@@ -231,7 +231,7 @@ def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mo
     q[3] = x[5]
     q[4] = 0
     ix = HipFlatIndex(d, metric)
-    assert ix.pass_queries == (64 if mode == "q64" else 32)
+    assert ix.pass_queries == (64 if mode in ("q64", "bf16") else 32)
     ix.add(x)
     _check(ix, x, q, k, metric)
     _check(ix, x, q[:1], 50, metric)
@@ -239,7 +239,7 @@ def test_all_scan_operand_modes_give_the_same_exact_results(gpu, monkeypatch, mo
     assert st["fallback_queries"] >= 1                   # so it took the exhaustive path
 
 
-@pytest.mark.parametrize("mode", ["split", "q64"])
+@pytest.mark.parametrize("mode", ["split", "q64", "bf16"])
 @pytest.mark.parametrize("nq", [65, 129, 256, 1100])
 def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
     """One scan launch runs several passes back to back (cyclic piece stream, query tile re-staged per pass): ragged
@@ -252,7 +252,7 @@ def test_multi_pass_launches(gpu, monkeypatch, mode, nq):
         q = ho.synthetic_queries(nq, d, seed=92)
         ix = HipFlatIndex(d, ho.METRIC_IP)
         ix.add(x)
-        assert ix.launch_queries == (1024 if mode == "q64" else 512)     # small index: 16 passes per launch
+        assert ix.launch_queries == (512 if mode == "split" else 1024)    # small index: 16 passes per launch
         _check(ix, x, q, 10, ho.METRIC_IP)
 
 
@@ -395,7 +395,7 @@ def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
         k = int(rng.choice([1, 5, 10, 31, 50, 57, 58, 64]))
         nq = int(rng.choice([1, 2, 63, 64, 65, 200, 300]))
         metric = [ho.METRIC_IP, ho.METRIC_L2][case % 2]
-        mode = ["q64", "q64", "split", "f32"][int(rng.integers(4))]
+        mode = ["bf16", "bf16", "q64", "split", "f32"][int(rng.integers(5))]
         monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
         x = ho.synthetic_vectors(n, d, seed=1000 + case)
         q = ho.synthetic_queries(nq, d, seed=2000 + case)
