@@ -4,16 +4,19 @@ bench.py -- headline benchmark of the MI355X hybrid-retrieval hot path.
 
 Metric (BASELINE.json): queries/sec (+ p50 retrieve latency) for exact top-10 inner-product search on a
 1M x 1024-d fp32 index.  Workload = BASELINE configs[1]: "1M x 1024-d synthetic vectors, brute-force
-inner-product top-10".  A STEP is one pass of the hot path over one batch of B=64 synthetic queries already
-resident in HBM: scan (fp32 MFMA, HBM-bound) -> group select -> fp64 re-score + certificate -> (N>1: one RCCL
-all-gather of the packed partial top-k + canonical merge).
+inner-product top-10".  A STEP is one pass of the hot path over one batch of synthetic queries already resident in
+HBM: ONE scan launch (8 passes of 64 queries at 1M rows; each pass streams the bf16 filter copy of the local rows
+once, HBM-bound) -> group select -> fp64 re-score of the fp32 rows + certificate (-> round B / exhaustive path where it
+fails) -> (N>1: one RCCL all-gather of the packed partial top-k + canonical merge).  Results are exact in every case.
 
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): the 1M rows are sharded row-wise
-across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to six steps are
+across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to four steps are
 in flight so the latency-bound tail of a step (selection, fp64 re-score, exchange, merge) runs beside later scans.
+The library sizes a launch by the local row count (16 passes = 1024 queries per step at <= 250k rows per GPU).
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     dominant kernel = scan_kernel; achieved = algorithmic bytes per launch (rows_local * d_pad * 4,
+  roofline     dominant kernel = scan_bf16_kernel; achieved = algorithmic bytes per launch (passes * rows_local * d_pad * 2:
+               the scan streams a 2-byte-per-element filter copy, the 4-byte rows are only touched by re-scoring;
                DESIGN.md) / mean launch duration from HIP events recorded on the launch stream around every scan
                launch of the timed region (in-kernel wall-clock stamps of the same launches beside them); peak 8000 GB/s (MI355X_MICROARCH.md).
   cpu_baseline the oracle's reference-faithful fp32 twin (one query per call, one thread) timed on this box's host
@@ -110,9 +113,9 @@ def main():
     gq.manual_seed(4321)
     queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
     queries /= queries.norm(dim=1, keepdim=True)
-    # one scan LAUNCH per step: 256 queries = 4 passes of 64 run back to back inside the launch (each pass streams the
-    # local rows once for its own query tile).  The library sizes a launch by the LOCAL row count so that it lasts about
-    # as long whatever the shard: 4 passes at 1M rows, 8 at 500k, 16 (1024 queries) at <= 250k rows per GPU.
+    # one scan LAUNCH per step: 512 queries = 8 passes of 64 run back to back inside the launch (each pass streams the
+    # bf16 copy of the local rows once for its own query tile).  The library sizes a launch by the LOCAL row count so that
+    # it lasts about as long whatever the shard: 8 passes at 1M rows, 16 (1024 queries) at <= 500k rows per GPU.
     # HIPRAG_LAUNCH_QUERIES / HIPRAG_SCAN_MODE change the split
     BATCH = index.launch_queries
     PASSES = (BATCH + index.pass_queries - 1) // index.pass_queries
@@ -181,7 +184,7 @@ def main():
         return
 
     qps = args.steps * BATCH / elapsed
-    # local rows * d_pad * 4 per pass, PASSES passes per launch: what ONE scan launch streams
+    # local rows * d_pad * 2 per pass (the bf16 filter copy), PASSES passes per launch: what ONE scan launch streams
     bytes_per_launch = int(st["bytes_per_pass"]) * PASSES
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {
@@ -195,7 +198,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16 x bf16 -> f32 filter scan, f64 re-score of the f32 rows",
         "data": "synthetic",
         "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
                    "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH, "passes_per_step": PASSES,
@@ -207,7 +210,7 @@ def main():
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "fallback_queries": int(st["fallback_queries"]),
         "build_s": round(build_s, 2),
-        "roofline": {"bound": "hbm", "kernel": "scan_split_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "scan_bf16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "bytes_per_launch": bytes_per_launch, "passes_per_launch": PASSES,
                      "avg_launch_ms": round(scan_ms, 5), "launches_timed": int(st["timed_passes"]),

@@ -6,7 +6,7 @@ import csv, glob, json, sys
 def collect(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and "scan_split_kernel" in r["Kernel_Name"] and ", true>" in r["Kernel_Name"]]
+            if r["Counter_Name"] == counter and ("scan_bf16_kernel" in r["Kernel_Name"] or "scan_split_kernel" in r["Kernel_Name"]) and ", true>" in r["Kernel_Name"]]
     # ", true>" = the multi-pass form of the template (single-query callers get the ", false>" form)
     vals = vals[3:]          # drop the first launches
     return {"launches": len(vals), "mean_kb": sum(vals) / len(vals), "min_kb": min(vals), "max_kb": max(vals)}
@@ -15,8 +15,8 @@ def collect(d, counter):
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 alg = int(sys.argv[4])
 fb, wb = fetch["mean_kb"] * 1024 * 2, write["mean_kb"] * 1024
-out = {"kernel": "scan_split_kernel<IP, 8 waves, 64-query tiles>, 4 passes per launch",
-       "workload": "1M x 1024 fp32 rows, 256 queries per launch (tools/seq_search.py: sequential hipidx_search_dev)",
+out = {"kernel": "scan_bf16_kernel<IP, 8 waves, ring 16, multi-pass>, 8 passes per launch",
+       "workload": "1M x 1024 rows (bf16 filter copy, 2.048 GB), 512 queries per launch (tools/seq_search.py: sequential hipidx_search_dev)",
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/seq_search.py",
                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/seq_search.py"],
        "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
