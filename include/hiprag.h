@@ -75,14 +75,20 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
  * float (may be NULL), out_ids_dev [nq,k] int64. */
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* Queries one scan pass serves: 64 in the default operand mode (bf16 hi/lo split of the index rows, hi-only query
- * tiles), 32 with HIPRAG_SCAN_MODE=split (hi/lo on both sides) or =f32 (exact fp32 MFMA).  All modes return the same
- * exact results; they differ in how wide the certificate's error bound is and how many rows get re-scored. */
+/* Queries one scan pass serves.  HIPRAG_SCAN_MODE picks the scan's operands:
+ *   bf16 (default)  64 queries; the scan streams a bf16 FILTER COPY of the rows (2 B per element, kept beside the fp32
+ *                   rows: 6 B per element of HBM in all) against bf16 query tiles
+ *   q64             64 queries; streams the fp32 rows, split on the fly into bf16 hi + lo, against hi-only query tiles
+ *   split           32 queries; hi + lo on both sides
+ *   f32             32 queries; exact fp32 MFMA (verification)
+ * All modes return the same exact results -- every candidate is re-scored in fp64 from the fp32 rows and a certificate
+ * (or, where it fails, a second finish round / the exhaustive path) proves nothing was missed; they differ in how many
+ * bytes a pass streams, how wide the certificate's error bound is and how many rows get re-scored. */
 int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n);
 /* Queries one scan LAUNCH takes (a multiple of the pass size): the scan kernel runs launch/pass passes back to back
  * inside one launch -- each pass streams the index once for its own query tile -- so that no kernel boundary (45-60 us
- * of idle GPU) separates them.  Sized by the index so that a launch lasts about 2.6 ms: 4 passes (256 queries) at
- * 1M x 1024, 8 at half that, 16 (the cap, 1024 queries) from a quarter down; it changes when rows are added.
+ * of idle GPU) separates them.  Sized by the index so that a launch lasts about 2.6 ms: in the default mode 8 passes
+ * (512 queries) at 1M x 1024, 16 (the cap, 1024 queries) from half that down; it changes when rows are added.
  * HIPRAG_LAUNCH_QUERIES fixes it.  The exact-fp32 mode runs one pass per launch. */
 int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
 /* Two-phase form of one launch (nq <= hipidx_launch_queries) for callers that pipeline: begin = index scan into
