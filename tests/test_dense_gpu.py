@@ -453,3 +453,29 @@ def test_deep_pipeline_with_changing_batch_shapes(gpu, monkeypatch, streams):
         es, ei = expect[(nq, k)]
         assert np.array_equal(ids.cpu().numpy(), ei), (nq, k)
         assert np.allclose(s32.cpu().numpy(), es, rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "q64", "split"])
+def test_near_ties_below_the_scan_resolution_stay_exact(gpu, monkeypatch, mode):
+    """Adversarial for the certificate: 3000 rows that differ from each other by 1e-6 .. 1e-4 relative -- far below what
+    the bf16 operands of the scan resolve -- surround the k-th score, together with random rows.  The scan cannot order
+    them; the certificate has to notice (round B or the exhaustive path) and the fp64 re-score decides: ids must equal
+    the oracle's, for unit and for scaled queries."""
+    from hiprag import HipFlatIndex
+    monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
+    rng = np.random.default_rng(123)
+    n, d, k = 20000, 512, 20
+    x = ho.synthetic_vectors(n, d, seed=55)
+    u = x[11].copy()
+    close = rng.choice(np.arange(100, n), size=3000, replace=False)
+    pert = rng.standard_normal((3000, d)).astype(np.float32)
+    pert /= np.linalg.norm(pert, axis=1, keepdims=True)
+    scale = (10.0 ** rng.uniform(-6, -4, size=(3000, 1))).astype(np.float32)
+    x[close] = u[None, :] + scale * pert
+    q = np.stack([u, 3.7 * u, u + 1e-5 * pert[0], -u]).astype(np.float32)
+    for metric in (ho.METRIC_IP, ho.METRIC_L2):
+        ix = HipFlatIndex(d, metric)
+        ix.add(x)
+        _check(ix, x, q, k, metric)
+        st = ix.stats()
+        assert st["roundb_queries"] + st["fallback_queries"] >= 1
