@@ -1202,8 +1202,13 @@ struct RoundBArgs {
     const float* tau;
     int* count;                // [nq]
     u32* slots;                // [nq][kRoundBGroups]
-    u64* bk;                   // [nq][kRoundBGroups * 16]
+    u64* bk;                   // [nq][kRoundBGroups * 4]: the tagged quad of every collected group
     i64* bi;
+    float* bsec;               // [nq][kRoundBGroups] `second` of every collected group
+    const float* gmax2;
+    const double* qn2;         // [nq][2] from the first round
+    const unsigned* max_norm2_bits;
+    int split;
     double* out64;
     float* out32;
     int64_t* out_ids;
@@ -1241,38 +1246,43 @@ __global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
     }
 }
 
-// grid (8, nq), 256 threads: wave g re-scores quad g of collected groups j = blockIdx.x, blockIdx.x + 8, ...
+// grid (8, nq), 256 threads: wave w re-scores the TAGGED quad of collected groups j = 4 * blockIdx.x + w, + 32, ...
 template <int METRIC>
 __global__ __launch_bounds__(256) void roundb_rescore_kernel(RoundBArgs a)
 {
     extern __shared__ float qv[];
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = blockIdx.y;
     if (!a.flags[q]) return;
     const int n = a.count[q];
-    if (n > kRoundBGroups || (int)blockIdx.x >= n) return;
+    if (n > kRoundBGroups || (int)blockIdx.x * 4 >= n) return;
     const int dpad = a.P * 8;
     for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
     __syncthreads();
-    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    for (int j = blockIdx.x * 4 + w; j < n; j += gridDim.x * 4) {
+        const i64 slot = (i64)a.slots[(int64_t)q * kRoundBGroups + j];
+        const int g = (int)(__float_as_uint(a.gmax[(int64_t)q * a.gstride + slot]) & 3u);
         int64_t blk;
         int gh;
-        group_decode((i64)a.slots[(int64_t)q * kRoundBGroups + j], a.bpw, a.nblocks, a.chunk, blk, gh);
+        group_decode(slot, a.bpw, a.nblocks, a.chunk, blk, gh);
         const int r0 = 8 * g + 4 * gh;
         const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
         const i64 row = blk * kRowsPerBlock + r0 + (lane & 3);
         if (lane < 4) {
-            const int64_t o = ((int64_t)q * kRoundBGroups + j) * 16 + g * 4 + lane;
+            const int64_t o = ((int64_t)q * kRoundBGroups + j) * 4 + lane;
             a.bk[o] = row < a.ntotal ? ord64(METRIC == HIPRAG_METRIC_IP ? s : -s) : 0ull;
             a.bi[o] = row;
         }
+        if (lane == 0) a.bsec[(int64_t)q * kRoundBGroups + j] = a.gmax2[(int64_t)q * a.gstride + slot];
     }
 }
 
-// one wave per query
+// one wave per query: exact top-k of the <= 1024 re-scored rows; groups whose `second` could still reach the k-th score
+// get their other three quads re-scored here (as in fin_final_kernel); every group with `first` >= tau is then covered
 template <int METRIC>
 __global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
 {
+    __shared__ float qv[kMaxDPad];
     const int q = blockIdx.x, lane = threadIdx.x;
     if (!a.flags[q]) return;
     const int n = a.count[q];
@@ -1280,9 +1290,9 @@ __global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
         if (lane == 0) atomicAdd(a.fallback_counter, 1ull);
         return;
     }
-    const int ncand = n * 16;
-    const u64* ck = a.bk + (int64_t)q * kRoundBGroups * 16;
-    const i64* ci = a.bi + (int64_t)q * kRoundBGroups * 16;
+    const int ncand = n * 4;
+    const u64* ck = a.bk + (int64_t)q * kRoundBGroups * 4;
+    const i64* ci = a.bi + (int64_t)q * kRoundBGroups * 4;
     u64 m = 0;
     for (int i = lane; i < ncand; i += 64) { const u64 kk = ck[i]; m = kk > m ? kk : m; }
     const u64 t0 = wave_kth_of_lanes(m, a.k);
@@ -1292,6 +1302,42 @@ __global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
         const int i = i0 + lane;
         const u64 kk = i < ncand ? ck[i] : 0ull;
         F.offer(kk >= t0 ? kk : 0ull, i < ncand ? ci[i] : -1, a.k);
+    }
+    const double qn2 = a.qn2[2 * q], dq2 = a.qn2[2 * q + 1];
+    const int dpad = a.P * 8;
+    const double eps = scan_eps<METRIC>(dpad, a.split, qn2, (double)__uint_as_float(a.max_norm2_bits[0]), dq2,
+                                        (double)__uint_as_float(a.max_norm2_bits[1]));
+    bool staged = false;
+    for (int j0 = 0; j0 < n; j0 += 64) {   // 64 groups at a time, one per lane
+        const int j = j0 + lane;
+        const float m2 = j < n ? a.bsec[(int64_t)q * kRoundBGroups + j] : -FLT_MAX;
+        unsigned long long done = 0;
+        for (;;) {
+            const double kth = kth_on_scan_scale<METRIC>(readlane_u64(F.k, a.k - 1), qn2);
+            const bool need = j < n && m2 > -1.0e38f && !(kth > (double)m2 + eps);
+            const unsigned long long mask = __ballot(need) & ~done;
+            if (!mask) break;
+            const int l = __builtin_ctzll(mask);
+            done |= 1ull << l;
+            if (!staged) {
+                for (int c = lane; c < dpad; c += 64) qv[c] = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
+                __syncthreads();
+                staged = true;
+            }
+            const i64 slot = (i64)a.slots[(int64_t)q * kRoundBGroups + j0 + l];
+            const int tagged = (int)(__float_as_uint(a.gmax[(int64_t)q * a.gstride + slot]) & 3u);
+            int64_t blk;
+            int gh;
+            group_decode(slot, a.bpw, a.nblocks, a.chunk, blk, gh);
+            for (int g = 0; g < 4; ++g) {
+                if (g == tagged) continue;
+                const int r0 = 8 * g + 4 * gh;
+                const double s = rescore4<METRIC>(a.xb, a.P, blk, r0, qv);
+                const i64 row = blk * kRowsPerBlock + r0 + (lane & 3);
+                const u64 key = (lane < 4 && row < a.ntotal) ? ord64(METRIC == HIPRAG_METRIC_IP ? s : -s) : 0ull;
+                F.offer(key, row, a.k);
+            }
+        }
     }
     if (lane < a.k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * a.k + lane, F.k, F.id, a.id_base);
     if (lane == 0) {
@@ -1605,8 +1651,8 @@ struct DenseIndex {
         if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
         // sel[Q][64] u64 | cand_k[Q][256] u64 | cand_i[Q][256] i64 | qn2[Q][2] f64 | sec[Q][64] f32
         if ((rc = w.fin.reserve(Q * (64 + 2 * kCandPerQuery + 2 + 32) * 8))) return rc;
-        // round B: tau[Q] f32 | count[Q] i32 | slots[Q][256] u32 | keys[Q][4096] u64 | ids[Q][4096] i64
-        if ((rc = w.rb.reserve(Q * (8 + kRoundBGroups * 4 + (size_t)kRoundBGroups * 16 * 16)))) return rc;
+        // round B: tau[Q] f32 | count[Q] i32 | slots[Q][256] u32 | sec[Q][256] f32 | keys[Q][1024] u64 | ids[Q][1024] i64
+        if ((rc = w.rb.reserve(Q * (8 + kRoundBGroups * 8 + (size_t)kRoundBGroups * 4 * 16)))) return rc;
         if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
         w.k = kk;
@@ -1723,8 +1769,9 @@ struct DenseIndex {
             float* rb_tau = w.rb.as<float>();
             int* rb_count = reinterpret_cast<int*>(rb_tau + w.q);
             u32* rb_slots = reinterpret_cast<u32*>(rb_count + w.q);
-            u64* rb_k = reinterpret_cast<u64*>(rb_slots + (size_t)w.q * kRoundBGroups);
-            i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)w.q * kRoundBGroups * 16);
+            float* rb_sec = reinterpret_cast<float*>(rb_slots + (size_t)w.q * kRoundBGroups);
+            u64* rb_k = reinterpret_cast<u64*>(rb_sec + (size_t)w.q * kRoundBGroups);
+            i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)w.q * kRoundBGroups * 4);
             fa.tau = rb_tau; fa.rb_count = rb_count;
             if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
@@ -1740,6 +1787,7 @@ struct DenseIndex {
             rb.out64 = o64p; rb.out32 = o32p; rb.out_ids = oidp; rb.fallback_counter = fallback_counter();
             rb.roundb_counter = roundb_counter(); rb.ntotal = ntotal; rb.id_base = id_base; rb.bpw = fa.bpw; rb.nblocks = nb;
             rb.d = d; rb.P = P; rb.k = k; rb.chunk = w.chunk;
+            rb.bsec = rb_sec; rb.gmax2 = fa.gmax2; rb.qn2 = fa.qn2; rb.max_norm2_bits = fa.max_norm2_bits; rb.split = fa.split;
             hipLaunchKernelGGL(roundb_collect_kernel, dim3((unsigned)std::max<int64_t>(1, (ngroups + 4095) / 4096), nq), dim3(256), 0, st, rb);
             hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(8, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
             hipLaunchKernelGGL(roundb_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, rb);
