@@ -1472,7 +1472,6 @@ struct DenseIndex {
     int d = 0, P = 0, metric = 0;
     int64_t ntotal = 0, cap_blocks = 0, id_base = 0;
     int n_cu = 256;
-    int scan_waves = 8;       // waves per scan workgroup (12 for the bf16 filter scan: three per SIMD)
     int scan_cus = 256;       // workgroups of a scan launch (one per CU); HIPRAG_SCAN_SPARE_CUS leaves some CUs to the tails
     int scan_mode = 3;        // HIPRAG_SCAN_MODE: f32 = 0 (exact fp32 MFMA), split = 1 (bf16 hi/lo of the fp32 rows, 32 q/pass),
                               // q64 = 2 (hi/lo rows x hi-only queries, 64 q/pass), bf16 = 3 (bf16 filter copy, 64 q/pass; default)
@@ -1516,8 +1515,6 @@ struct DenseIndex {
         hipDeviceProp_t prop;
         HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const char* swv = getenv("HIPRAG_SCAN_WAVES");
-        scan_waves = swv && atoi(swv) == 12 ? 12 : 8;
         const char* sp = getenv("HIPRAG_SCAN_SPARE_CUS");
         scan_cus = std::max(1, n_cu - (sp ? atoi(sp) : 0));
         const char* ms = getenv("HIPRAG_SCAN_MODE");
@@ -1689,11 +1686,9 @@ struct DenseIndex {
             const int P2 = P / 2;
             const bool one_pass = nq <= 64;
             void (*scan)(ScanArgs);
-            int nw = 8;
-            if (P2 % 16 == 0) {
-                if (scan_waves == 12) { scan = one_pass ? scan_bf16_kernel<METRIC, 12, 16, false> : scan_bf16_kernel<METRIC, 12, 16, true>; nw = 12; }
-                else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false> : scan_bf16_kernel<METRIC, 8, 16, true>;
-            } else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 8, false> : scan_bf16_kernel<METRIC, 8, 8, true>;
+            const int nw = 8;   // a third wave per SIMD (12 per workgroup) does not fit 168 registers: 83 spills
+            if (P2 % 16 == 0) scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false> : scan_bf16_kernel<METRIC, 8, 16, true>;
+            else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 8, false> : scan_bf16_kernel<METRIC, 8, 8, true>;
             w.waves = nw;
             w.chunk = 8;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
