@@ -71,6 +71,10 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 // lists are read whole by every tile and filtered -- 61 tiles x < 2048 postings costs less than a table lookup chain.
 // Determinism: a document occurs at most once per list, so within a slot no two threads touch the same accumulator and
 // the barrier between slots keeps every document's fp32 sum in query-term order, exactly the oracle's.
+// Selection: grid (nq, ntiles), queries fastest.  theta[q] (zeroed per launch) carries the best K-th score any finished
+// wave of query q has published, as order-preserving u32 bits; a wave whose own maximum is below it emits nothing, one
+// with few survivors above it skips the threshold bisection.  A bound is only ever a score K documents already reached,
+// so dropping what lies strictly below it cannot change the merged top-k (ties at the bound are kept).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTileDocs = 16384;
 constexpr u64 kSkipMinDf = 2048;
@@ -84,15 +88,17 @@ struct TileSlot {   // posting range of one (query, term slot); skip = first ent
 __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ doc_ids, const float* __restrict__ impacts,
                                                         const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
                                                         const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
-                                                        u64* __restrict__ ck, i64* __restrict__ ci,
+                                                        u64* __restrict__ ck, i64* __restrict__ ci, u32* __restrict__ theta,
                                                         unsigned long long* __restrict__ dbg)
 {
     extern __shared__ float tacc[];  // kTileDocs accumulators
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x, q = blockIdx.y;
+    // queries fastest: the tiles of one query are spread over the whole launch, so the bound its early tiles publish
+    // (theta, below) is there when the later ones select; neighbours in time share a tile's postings of common terms
+    const int q = blockIdx.x, tile = blockIdx.y;
     const u32 tlo = (u32)tile * kTileDocs;
     const u32 tlen = (u32)min((i64)kTileDocs, n_docs - (i64)tlo);
-    unsigned long long* dp = dbg ? dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    unsigned long long* dp = dbg ? dbg + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
     if (dp && threadIdx.x == 0) dp[0] = wall_clock64();
     // posting ranges of this tile for every slot, resolved up front (slot descriptor -> skip table is a chain of two
     // dependent global loads; done per slot inside the loop it cost ~4 us of latency six times per workgroup)
@@ -165,19 +171,32 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NV * 4; ++n) m = fmaxf(m, v[n] > 0.f ? v[n] : -INFINITY);
     const u32 mo = m == -INFINITY ? 0u : ord32(m);
+    // theta[q] = the best K1-th score any finished wave of this query has published (ordered-integer form, grows
+    // monotonically): a lower bound of the query's final K1-th score, so nothing below it can reach the result.  The
+    // first tiles of a query pay the full selection; later ones start from a threshold that is already almost final
+    // and keep only a handful of documents.  Which tiles profit depends on timing, the merged top-k does not.
+    const u32 th = __hip_atomic_load(theta + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 best = 0;
-    for (int j = 0; j < 64; ++j) {
-        const u32 mj = (u32)__builtin_amdgcn_readlane((int)mo, j);
-        const int cnt = __popcll(__ballot(mo >= mj));
-        if (mj != 0 && cnt >= K1 && mj > best) best = mj;
-    }
-    if (best) {
+    u32 top = mo;
 #pragma unroll
-        for (int n = 0; n < NV * 4; ++n) v[n] = v[n] > 0.f ? v[n] : -INFINITY;
-        u32 top = mo;
+    for (int off = 32; off >= 1; off >>= 1) top = max(top, (u32)__shfl_xor((int)top, off));
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) top = max(top, (u32)__shfl_xor((int)top, off));
-        best = wave_bisect_threshold(v, best, top + 1, K1, 10);
+    for (int n = 0; n < NV * 4; ++n) v[n] = v[n] > 0.f ? v[n] : -INFINITY;
+    if (th != 0 && th > top) {
+        best = th;                       // nothing in this wave's range can reach the result
+    } else if (th != 0) {
+        const float tf = unord32(th);
+        int c = 0;
+#pragma unroll
+        for (int n = 0; n < NV * 4; ++n) c += __popcll(__ballot(v[n] >= tf));
+        best = c > K1 + (K1 >> 1) ? wave_bisect_threshold(v, th, top + 1, K1, 10) : th;
+    } else {
+        for (int j = 0; j < 64; ++j) {
+            const u32 mj = (u32)__builtin_amdgcn_readlane((int)mo, j);
+            const int cnt = __popcll(__ballot(mo >= mj));
+            if (mj != 0 && cnt >= K1 && mj > best) best = mj;
+        }
+        if (best) best = wave_bisect_threshold(v, best, top + 1, K1, 10);
     }
     if (dp && tid == 0) dp[3] = wall_clock64();
     WaveListPacked L;
@@ -191,10 +210,12 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
         tau = L.offer(c, K1, tau);
     }
     if (lane < K1) {
-        const i64 o = (((i64)q * gridDim.x + tile) * 4 + wv) * K1 + lane;
+        const i64 o = (((i64)q * gridDim.y + tile) * 4 + wv) * K1 + lane;
         ck[o] = L.e & 0xFFFFFFFF00000000ull;
         ci[o] = L.e ? (i64)packed_index(L.e) : -1;
     }
+    const u64 kth = L.kth(K1);   // this wave holds K1 documents at or above it: publish the bound
+    if (lane == 0 && kth != 0) atomicMax(theta + q, (u32)(kth >> 32));
     if (dp && tid == 0) dp[4] = wall_clock64();
 }
 
@@ -235,7 +256,7 @@ struct Bm25Index {
     int device = 0;
     i64 n_docs = 0, n_terms = 0, n_postings = 0, id_base = 0;
     std::vector<uint64_t> offsets;  // host copy: planning happens on the host
-    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg;
+    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg, theta_dev;
     std::vector<i64> skip_index;         // per term: first entry of its skip table, or -1 (short lists)
     std::vector<TileSlot> plan_slots;    // host staging of the last query plan (kept alive for the async copy)
     std::vector<int> plan_nslots;
@@ -294,15 +315,17 @@ struct Bm25Index {
         if ((rc = ci.reserve((size_t)nq * lists * k * sizeof(i64)))) return rc;
         HR_CHECK_HIP(hipMemcpyAsync(slots_dev.p, plan_slots.data(), plan_slots.size() * sizeof(TileSlot), hipMemcpyHostToDevice, st));
         HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots.data(), plan_nslots.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        if ((rc = theta_dev.reserve((size_t)nq * sizeof(u32)))) return rc;
+        HR_CHECK_HIP(hipMemsetAsync(theta_dev.p, 0, (size_t)nq * sizeof(u32), st));
         static bool lds_ok = false;
         if (!lds_ok) {
             HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              kTileDocs * (int)sizeof(float)));
             lds_ok = true;
         }
-        hipLaunchKernelGGL(taat_tile_kernel, dim3((unsigned)ntiles(), nq), dim3(256), kTileDocs * sizeof(float), st,
+        hipLaunchKernelGGL(taat_tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(256), kTileDocs * sizeof(float), st,
                            doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
-                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), dbg_p);
+                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), dbg_p);
         if (dbg_p) {
             HR_CHECK_HIP(hipStreamSynchronize(st));
             std::vector<unsigned long long> h((size_t)nq * ntiles() * 8);
