@@ -25,6 +25,8 @@ class Config:
     HIP_INDEX_METRIC = os.getenv("HIP_INDEX_METRIC", "l2")       # the reference builds IndexFlatL2 (faiss_index.py:123)
     HIP_DEVICE = int(os.getenv("HIP_DEVICE", "0"))
     HIP_COMPAT_MINUS_ONE = os.getenv("HIP_COMPAT_MINUS_ONE", "true").lower() == "true"
+    # false (default): search the FIRST index file only, like the reference (faiss_index.py:162-167); true: every document
+    HIP_SEARCH_ALL_DOCUMENTS = os.getenv("HIP_SEARCH_ALL_DOCUMENTS", "false").lower() == "true"
 
     @property
     def STORAGE_DIR(self) -> Path:

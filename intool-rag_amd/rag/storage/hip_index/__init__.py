@@ -21,6 +21,8 @@ Differences, all deliberate and listed in DESIGN.md:
   * index files are `{doc_id}_hip.index` (HIPIDX01: header + row-major fp32), not FAISS's binary format;
   * the chunk table (`{doc_id}_chunks.json`) is parsed once per file version and cached -- the reference re-parses it on
     every query (:172-176);
+  * HIP_SEARCH_ALL_DOCUMENTS=true searches every document's index and merges (the reference, and the default here,
+    search only the first file, :162-167);
   * HIP_COMPAT_MINUS_ONE=true (default) keeps the reference's quirk that an id of -1 (k > ntotal) passes
     `faiss_id < len(chunks)` and indexes the LAST chunk with score 0 (:179-181); set it to false to drop such rows.
 """
@@ -211,10 +213,51 @@ def open_first_index():
     return HipIndexReader(str(index_path)), doc_id, _load_chunk_list(storage_path, doc_id)
 
 
+def open_all_indices():
+    """[(reader, doc_id, chunk list)] of EVERY document under STORAGE_DIR, in file-name order (a `_hip.index` file wins
+    over the same document's `_faiss.index`).  Documents whose chunk table is missing are skipped with a warning."""
+    storage_path = Path(config.STORAGE_DIR)
+    by_doc: Dict[str, Path] = {}
+    for suffix in (FAISS_SUFFIX, INDEX_SUFFIX):            # later suffix overrides
+        for f in storage_path.glob(f"*{suffix}"):
+            by_doc[f.name[:-len(suffix)]] = f
+    opened = []
+    for doc_id in sorted(by_doc):
+        try:
+            chunks = _load_chunk_list(storage_path, doc_id)
+        except FileNotFoundError as e:
+            logger.warning(f"Skipping {doc_id}: {e}")
+            continue
+        opened.append((HipIndexReader(str(by_doc[doc_id])), doc_id, chunks))
+    return opened
+
+
+def search_all_documents(query_vector: List[float], limit: int = 50) -> List[dict]:
+    """Multi-document search (the reference stops at the first file, faiss_index.py:162-167): the top `limit`
+    of every document's index, enriched against that document's own chunk table, merged by (score desc, document
+    order, rank inside the document) and cut to `limit`.  Scores are the same clamp(1 - d/2) on unit vectors in every
+    document, so they compare across documents.  Padding rows (id -1, k > ntotal) never enter the merge."""
+    merged = []
+    for di, (reader, doc_id, chunks_list) in enumerate(open_all_indices()):
+        results = [r for r in reader.search(query_vector, top_k=limit) if r[0] >= 0]
+        for rank, row in enumerate(enrich(results, chunks_list, compat_minus_one=False)):
+            row["doc_id"] = doc_id
+            merged.append((-row["score"], di, rank, row))
+    merged.sort(key=lambda t: t[:3])
+    return [t[3] for t in merged[:limit]]
+
+
 async def search_hip_by_vector(query_vector: List[float], limit: int = 50, project: Optional[str] = None) -> List[dict]:
     """Main search function of the query pipeline (faiss_index.py:137-199): first index file in STORAGE_DIR, enriched
-    results; `project` is accepted and ignored like in the reference; no index -> [] with a warning."""
+    results; `project` is accepted and ignored like in the reference; no index -> [] with a warning.
+    HIP_SEARCH_ALL_DOCUMENTS=true searches every document instead (search_all_documents)."""
     try:
+        if config.HIP_SEARCH_ALL_DOCUMENTS:
+            enriched_results = search_all_documents(query_vector, limit)
+            if not enriched_results:
+                logger.warning("No HIP indices found")
+            logger.info(f"HIP search returned {len(enriched_results)} results")
+            return enriched_results
         opened = open_first_index()
         if opened is None:
             logger.warning("No HIP indices found")
@@ -261,4 +304,5 @@ def clear_caches() -> None:
 
 
 __all__ = ["HipIndexReader", "create_hip_index", "save_hip_index", "search_hip_by_vector", "initialize_storage",
-           "enrich", "clear_caches", "open_first_index", "HAS_HIP", "INDEX_SUFFIX"]
+           "enrich", "clear_caches", "open_first_index", "open_all_indices", "search_all_documents", "HAS_HIP",
+           "INDEX_SUFFIX"]

@@ -249,6 +249,51 @@ def test_overlay_reads_index_files_written_by_the_reference_format(gpu, tmp_path
     hi.clear_caches()
 
 
+def test_multi_document_search_merges_every_index(gpu, tmp_path, monkeypatch):
+    """HIP_SEARCH_ALL_DOCUMENTS (SURVEY 8f2): every document's index is searched and the enriched rows merge by score;
+    the default still answers from the first file only (faiss_index.py:162-167)."""
+    import rag.storage.hip_index as hi
+    from hiprag.faiss_io import write_faiss_flat
+    from oracle import hybrid_oracle as ho
+    monkeypatch.setenv("STORAGE_DIR", str(tmp_path))
+    hi.clear_caches()
+    rng = np.random.default_rng(99)
+    docs = {"a_manual": 40, "b_short": 7, "c_report": 100}            # b_short is smaller than the limit: -1 padding
+    rows = {}
+    for n, (doc, cnt) in enumerate(docs.items()):
+        x = rng.standard_normal((cnt, 64)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        rows[doc] = x
+        if doc == "c_report":                                          # one document still in the reference's format
+            write_faiss_flat(str(tmp_path / f"{doc}_faiss.index"), x, 1)
+        else:
+            hi.save_hip_index(hi.create_hip_index(x, metric="l2"), str(tmp_path / f"{doc}{hi.INDEX_SUFFIX}"))
+        chunks = [{"chunk_id": f"{doc}_{i}", "text": f"{doc} text {i}", "page": i // 4 + 1,
+                   "metadata": {"title": doc, "source_filename": f"{doc}.pdf"}} for i in range(cnt)]
+        with open(tmp_path / f"{doc}_chunks.json", "w") as f:
+            json.dump({"chunks": chunks}, f)
+    hi.clear_caches()
+    q = rows["c_report"][17] + 0.3 * rows["a_manual"][5] + 0.2 * rows["b_short"][2]
+    q = (q / np.linalg.norm(q)).astype(np.float32)
+    limit = 10
+    expected = []
+    for di, doc in enumerate(sorted(docs)):
+        d, i = ho.flat_search(rows[doc], q, limit, ho.METRIC_L2)
+        for rank, (rid, score) in enumerate(r for r in ho.reader_search_transform(d[0], i[0]) if r[0] >= 0):
+            expected.append((-score, di, rank, f"{doc}_{rid}"))
+    expected.sort()
+    monkeypatch.setattr(hi.config, "HIP_SEARCH_ALL_DOCUMENTS", True, raising=False)
+    got = asyncio.run(hi.search_hip_by_vector([float(v) for v in q], limit=limit))
+    assert [r["chunk_id"] for r in got] == [e[3] for e in expected[:limit]]
+    assert np.allclose([r["score"] for r in got], [-e[0] for e in expected[:limit]], rtol=0, atol=1e-4)
+    assert got[0]["chunk_id"] == "c_report_17" and {r["doc_id"] for r in got} >= {"a_manual", "c_report"}
+    assert all(r["source_filename"] == r["doc_id"] + ".pdf" for r in got)
+    monkeypatch.setattr(hi.config, "HIP_SEARCH_ALL_DOCUMENTS", False, raising=False)
+    first = asyncio.run(hi.search_hip_by_vector([float(v) for v in q], limit=limit))
+    assert len({r["chunk_id"].rsplit("_", 1)[0] for r in first}) == 1          # one document only, like the reference
+    hi.clear_caches()
+
+
 def test_ingest_indexing_then_retrieval_config1_scale(gpu, tmp_path, monkeypatch):
     """BASELINE configs[0] shape end to end on the GPU: 10k chunks -> index_chunks (embed_batch on the encoder, vectors
     straight from HBM into the index, postings from the same texts; rag/ingest/ingestion_pipeline.py:80-94) ->
