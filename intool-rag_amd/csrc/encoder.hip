@@ -15,13 +15,17 @@
 //   K6/K8/K9 gemm_bf16_kernel 128x128x64 LDS-tiled GEMM, C = A[M,K] * W[N,K]^T, fused epilogues:
 //            QKV (bias, 1/8 scale on q, head-major q/k and TRANSPOSED v), GELU (bias + erf-GELU), RESID (bias + residual
 //            -> fp32 pre-LayerNorm buffer)
+//            gemm_skinny_kernel: the same products for <= 512 token rows (one query, a few short texts) as
+//            weight-streaming workgroups of 16/32 columns; split-K partials are summed by the LayerNorm
 //   K7  attention_kernel     flash-style, computed transposed: 128 queries x 64-key tiles, online softmax in fp32, P stays in registers
 //       layernorm_kernel     fp32 pre-LN rows -> bf16
 //   K10 pool_kernel / rerank_head_kernel
 // LDS tiles are stored k-chunk-major ([k/8][row][8 bf16]) with row ^= (chunk & 7): fragment reads (ds_read_b128) and
 // the staging writes are both bank-conflict free (checked by brute force over the ds_read_b128 lane groups).
 // Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s); flops/token ~ L*(8H^2 + 4HF) + attention.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -215,6 +219,147 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Small-batch GEMM (the single-query latency path: embed_single / a handful of short texts, rows <= ~1024).
+// With 64..1024 activation rows the 128x128 tiles above leave 8..32 workgroups walking K serially (40 us for the F->H
+// GEMM of one query); here the work is what it really is -- streaming the weight matrix once: a workgroup owns 16 output
+// columns over a K range of <= 1024 (its four waves a quarter each, W fragments loaded straight from HBM in MFMA layout,
+// 16 B per lane, and kept in registers), multiplies them with up to four 64-row blocks of A (fragments from L2), sums the
+// four waves' partial tiles through LDS in a fixed order and runs the epilogue.  K > 1024 splits over workgroups
+// (ksplit = K / Kc) which write raw fp32 partials [ksplit][M][N]; the LayerNorm that follows adds them up in split order,
+// so there are no atomics and results do not depend on scheduling.
+// ---------------------------------------------------------------------------------------------------------
+enum { EPI_PART = 3 };
+constexpr int SK_STEPS = 8;   // 32-deep MFMA steps per wave (K range per workgroup <= 4 * 8 * 32 = 1024)
+
+// NT: 16-column tiles per wave (the workgroup owns 16 * NT output columns; NT = 2 halves the L2 reads of A, which every
+// column tile repeats, and is used from 128 rows up).  FULL: the K range per workgroup is exactly 1024 (the real model:
+// H = 1024, F = 4096) -- every load is issued before the first MFMA; otherwise a plain loop over `steps`.
+template <int EPI, int NT, bool FULL>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g, int kc, int steps, int mb_per_wg)
+{
+    constexpr int WN = 16 * NT;
+    __shared__ float red[4][64][WN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int ntile = g.N / WN;
+    const int split = blockIdx.x / ntile, n0 = (blockIdx.x - split * ntile) * WN;
+    const int kw0 = split * kc + wave * (kc >> 2);
+    const size_t k16 = (size_t)16 * g.K;
+
+    const bf16* wp = g.W + (size_t)(n0 + r16) * g.K + kw0 + kq * 8;
+    bf16x8 bfr[NT][SK_STEPS];
+    if (FULL) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int s = 0; s < SK_STEPS; ++s) bfr[j][s] = *reinterpret_cast<const bf16x8*>(wp + j * k16 + s * 32);
+    }
+
+    const int mb0 = blockIdx.y * mb_per_wg, mb1 = min(mb0 + mb_per_wg, g.M >> 6);
+    for (int mb = mb0; mb < mb1; ++mb) {
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16* ap = g.A + (size_t)(mb * 64 + r16) * g.K + kw0 + kq * 8;
+        if (FULL) {
+            bf16x8 af[4][SK_STEPS];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < SK_STEPS; ++s) af[i][s] = *reinterpret_cast<const bf16x8*>(ap + i * k16 + s * 32);
+            __builtin_amdgcn_sched_barrier(0);  // all 32 (+ 8 NT) loads in flight before the first MFMA waits: one round trip
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < SK_STEPS; ++s)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < steps; ++s) {
+                bf16x8 b[NT], a[4];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(wp + j * k16 + s * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ap + i * k16 + s * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * kq + r][j * 16 + r16] = acc[i][j][r];
+        __syncthreads();
+
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        if (EPI == EPI_QKV && n0 >= 2 * g.H) {
+            // V third, stored transposed [seq, head, d, S]: one column x 4 consecutive tokens -> one 8-B store
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                const int ch = tid + 256 * e;
+                const int col = ch % WN, rg = (ch / WN) * 4;
+                const int n = n0 + col, hn = n - 2 * g.H;
+                const int head = hn >> 6, dd = hn & 63;
+                const float bias = g.bias[n];
+                const int m = mb * 64 + rg;
+                const int seq = m / g.S, s0 = m - seq * g.S;
+                bf16x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = (bf16)((((red[0][rg + u][col] + red[1][rg + u][col]) + red[2][rg + u][col]) + red[3][rg + u][col]) + bias);
+                *reinterpret_cast<bf16x4*>(g.vt + (((size_t)seq * g.heads + head) * 64 + dd) * g.S + s0) = v;
+            }
+        } else {
+            // row-major outputs: 4 consecutive columns of one row per item
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                const int ch = tid + 256 * e;
+                const int row = ch / (4 * NT), c4 = (ch % (4 * NT)) * 4;
+                const int m = mb * 64 + row, n = n0 + c4;
+                const float4 p0 = *reinterpret_cast<const float4*>(&red[0][row][c4]);
+                const float4 p1 = *reinterpret_cast<const float4*>(&red[1][row][c4]);
+                const float4 p2 = *reinterpret_cast<const float4*>(&red[2][row][c4]);
+                const float4 p3 = *reinterpret_cast<const float4*>(&red[3][row][c4]);
+                float x[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                              ((p0.w + p1.w) + p2.w) + p3.w};
+                if (EPI == EPI_PART) {
+                    *reinterpret_cast<float4*>(g.out_f32 + ((size_t)split * g.M + m) * g.N + n) = make_float4(x[0], x[1], x[2], x[3]);
+                } else {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+                    x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+                    bf16x4 o;
+                    if (EPI == EPI_QKV) {
+                        const int which = n / g.H, hn = n - which * g.H;   // 0 (q) or 1 (k)
+                        const int head = hn >> 6, dd = hn & 63;
+                        const int seq = m / g.S, s = m - seq * g.S;
+                        const float scale = which == 0 ? 0.125f : 1.f;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) o[u] = (bf16)(x[u] * scale);
+                        bf16* dst = (which == 0 ? g.q : g.k) + ((((size_t)seq * g.heads + head) * g.S + s) * 64 + dd);
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    } else {  // EPI_GELU
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) o[u] = (bf16)(0.5f * x[u] * (1.f + erf_as(x[u] * 0.70710678118654752f)));
+                        *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.N + n) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the partial tiles are free for the next row block
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LayerNorm over rows of an fp32 [M,H] buffer -> bf16; one wave per row.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
@@ -224,9 +369,13 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// PARTS: the row is the sum of `nsplit` fp32 partial products (gemm_skinny_kernel<EPI_PART>, split order) + bias + the
+// bf16 residual row -- the same (c + bias) + residual order as the EPI_RESID epilogue of the tiled GEMM.
+template <bool PARTS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, bf16* __restrict__ y, int M, int H,
-                                                       float eps)
+                                                       float eps, int nsplit, const float* __restrict__ bias,
+                                                       const bf16* __restrict__ resid)
 {
     // one wave per row; the row is read ONCE (16 B per lane per load, kept in registers: H <= 2048 -> <= 8 float4)
     const int lane = threadIdx.x & 63;
@@ -241,6 +390,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < 8; ++i) {
         const int c = i * 64 + lane;
         v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PARTS && c < nvec) {
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp) {
+                if (sp < nsplit) {
+                    const float4 p = xr[(size_t)sp * M * (H >> 2) + c];
+                    v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
+                }
+            }
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4r;
+            const float4 b = reinterpret_cast<const float4*>(bias)[c];
+            const bf16x4r rs = reinterpret_cast<const bf16x4r*>(resid + (size_t)row * H)[c];
+            v[i].x = (v[i].x + b.x) + (float)rs[0]; v[i].y = (v[i].y + b.y) + (float)rs[1];
+            v[i].z = (v[i].z + b.z) + (float)rs[2]; v[i].w = (v[i].w + b.w) + (float)rs[3];
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     (void)nv;
@@ -505,6 +668,31 @@ struct Encoder {
     std::vector<hipenc_layer_weights> layers;
     DevBuf tokens, lens, x, q, k, vt, ctx, pre, ffn, pooled;
     double flops_last = 0.0;
+    int small_rows = 512;    // batches of at most this many (padded) token rows take the small-batch GEMM; 0 = never
+                             // (HIPENC_SMALL_ROWS; measured crossover with the tiled GEMM ~1024 rows)
+
+    // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
+    static int skinny_split(int K) { return (K + 1023) / 1024; }
+    static bool skinny_ok(int K) { const int sp = skinny_split(K); return K % (sp * 128) == 0; }
+
+    template <int EPI>
+    static void launch_skinny(GemmArgs a, hipStream_t st)
+    {
+        const int sp = skinny_split(a.K), kc = a.K / sp, steps = kc / 128;
+        const bool wide = a.M >= 128 && a.N % 32 == 0;     // two column tiles per wave: half the L2 reads of A
+        // row blocks run one after the other inside a workgroup (a round trip to L2 each): spread them over workgroups
+        // until the launch has ~1024 of them, W comes out of L2 for all but the first
+        const int gx = (a.N / (wide ? 32 : 16)) * sp, mblocks = a.M >> 6;
+        const int mb = std::max(1, (gx * mblocks + 1023) / 1024);
+        const dim3 grid(gx, (mblocks + mb - 1) / mb);
+        if (steps == SK_STEPS) {
+            if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, true>), grid, dim3(256), 0, st, a, kc, steps, mb);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, true>), grid, dim3(256), 0, st, a, kc, steps, mb);
+        } else {
+            if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, false>), grid, dim3(256), 0, st, a, kc, steps, mb);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, false>), grid, dim3(256), 0, st, a, kc, steps, mb);
+        }
+    }
 
     int32_t forward(const int32_t* tok_host, const int32_t* lens_host, int nseq, int max_len, float* out_dev, int mode,
                     hipStream_t st)
@@ -521,7 +709,10 @@ struct Encoder {
         if ((rc = k.reserve((size_t)M * H * 2))) return rc;
         if ((rc = vt.reserve((size_t)M * H * 2))) return rc;
         if ((rc = ctx.reserve((size_t)M * H * 2))) return rc;
-        if ((rc = pre.reserve((size_t)M * H * 4))) return rc;
+        // one query / a few short texts: weight-streaming GEMMs instead of 128 x 128 tiles (S is a multiple of 64, so is T)
+        const bool small = small_rows > 0 && T <= small_rows && H <= 1024 && skinny_ok(H) && skinny_ok(F) && skinny_split(F) <= 4;
+        const int fsplit = skinny_split(F);
+        if ((rc = pre.reserve((size_t)M * H * 4 * (small ? fsplit : 1)))) return rc;
         if ((rc = ffn.reserve((size_t)M * F * 2))) return rc;
         // host staging: pad token rows to S with pad_id
         std::vector<int32_t> tp((size_t)nseq * S, cfg.pad_id);
@@ -549,26 +740,46 @@ struct Encoder {
             g.q = q.as<bf16>(); g.k = k.as<bf16>(); g.vt = vt.as<bf16>(); g.S = S; g.heads = heads; g.H = H;
             // rows >= T exist only as GEMM padding; the QKV scatter must not write them
             g.M = T;
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
+            if (small) launch_skinny<EPI_QKV>(g, st);
+            else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
             hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
                                (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
                                heads, H);
             GemmArgs o{};
             o.A = ctx.as<bf16>(); o.W = (const bf16*)L.wo; o.bias = (const float*)L.bo; o.M = M; o.N = H; o.K = H;
             o.resid = X; o.out_f32 = pre.as<float>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, o);
-            hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
-                               (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps);
+            if (small) {
+                o.M = T;
+                launch_skinny<EPI_PART>(o, st);
+                hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), T, H, cfg.ln_eps, skinny_split(H),
+                                   (const float*)L.bo, X);
+            } else {
+                hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, o);
+                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
+                                   (const float*)nullptr, (const bf16*)nullptr);
+            }
             GemmArgs f1{};
             f1.A = X; f1.W = (const bf16*)L.w1; f1.bias = (const float*)L.b1; f1.M = M; f1.N = F; f1.K = H;
             f1.out_bf16 = ffn.as<bf16>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3((F / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f1);
+            if (small) { f1.M = T; launch_skinny<EPI_GELU>(f1, st); }
+            else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3((F / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f1);
             GemmArgs f2{};
             f2.A = ffn.as<bf16>(); f2.W = (const bf16*)L.w2; f2.bias = (const float*)L.b2; f2.M = M; f2.N = H; f2.K = F;
             f2.resid = X; f2.out_f32 = pre.as<float>();
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f2);
-            hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
-                               (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps);
+            if (small) {
+                f2.M = T;
+                launch_skinny<EPI_PART>(f2, st);
+                hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), T, H, cfg.ln_eps, fsplit,
+                                   (const float*)L.b2, X);
+            } else {
+                hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f2);
+                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
+                                   (const float*)nullptr, (const bf16*)nullptr);
+            }
         }
         if (mode == 0 || mode == 2) {
             hipLaunchKernelGGL(pool_kernel, dim3(nseq), dim3(64), 0, st, X, (const int*)lens.as<int>(), S, H, out_dev,
@@ -612,6 +823,7 @@ int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, i
     e->cfg = *cfg;
     e->w = *weights;
     e->layers.assign(weights->layers, weights->layers + cfg->layers);
+    if (const char* sr = std::getenv("HIPENC_SMALL_ROWS")) e->small_rows = std::atoi(sr);
     for (const auto& L : e->layers)
         HR_REQUIRE(L.wqkv && L.bqkv && L.wo && L.bo && L.ln1_g && L.ln1_b && L.w1 && L.b1 && L.w2 && L.b2 && L.ln2_g && L.ln2_b,
                    "null layer weight pointer");

@@ -57,6 +57,24 @@ def test_batching_does_not_change_results(gpu):
     assert np.allclose(got, again, atol=2e-3)          # same kernels, different padding: only rounding-order noise
 
 
+def test_small_batch_gemm_path_matches_tiled_path_and_oracle(gpu, monkeypatch):
+    """The single-query latency path (weight-streaming GEMMs with split-K partials summed in the LayerNorm, rows <=
+    HIPENC_SMALL_ROWS) against the 128x128-tile path on the same inputs, and both against the fp32 oracle."""
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    for cfg, lens in [(EncoderConfig(vocab=3000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=300), [12, 40, 64, 100, 1, 129]),
+                      (EncoderConfig(vocab=1000, hidden=384, layers=2, heads=6, ffn=1536, max_pos=300), [7, 64, 65, 130, 200])]:
+        monkeypatch.setenv("HIPENC_SMALL_ROWS", "1024")
+        enc, sd, toks, small, ref = _check(cfg, lens, seed=11, batch_size=4)          # T <= 4 * 256 rows: the small path
+        # (rows 64..1024: one and two column tiles per wave, one and several row blocks per workgroup)
+        one = enc.encode_tokens(toks[:1], batch_size=1).cpu().numpy()                  # one query alone
+        monkeypatch.setenv("HIPENC_SMALL_ROWS", "0")
+        tiled = HipEncoder(cfg, sd).encode_tokens(toks, batch_size=4).cpu().numpy()
+        assert np.allclose(small, tiled, atol=2e-3)
+        assert np.allclose(one[0], small[0], atol=2e-3)
+        again = enc.encode_tokens(toks, batch_size=4).cpu().numpy()
+        assert np.array_equal(again, small)                                            # no atomics: run-to-run identical
+
+
 def test_reranker_head_logits(gpu):
     from hiprag import EncoderConfig
     cfg = EncoderConfig(vocab=1000, hidden=256, layers=2, heads=4, ffn=1024, max_pos=300)
