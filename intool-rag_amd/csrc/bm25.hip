@@ -117,45 +117,69 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     for (int i = tid; i < kTileDocs / 4; i += 256) reinterpret_cast<float4*>(tacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (dp && tid == 0) dp[1] = wall_clock64();
-    // The slots form ONE stream of 2048-posting chunks: the loads of the next chunk -- of the same slot or of the next
-    // one -- are in flight while this chunk's accumulator updates run; a workgroup barrier separates slots only.
+    // The slots form ONE stream of 2048-posting chunks: the loads of the next chunks -- of the same slot or of the next
+    // ones -- are in flight while this chunk's accumulator updates run; a workgroup barrier separates slots only.
     constexpr int U = 8;
     constexpr u64 CH = (u64)U * 256;
+    // Loads are UNCONDITIONAL (lanes past the end of a range read posting 0, the buffers never have fewer than four
+    // entries) and nothing touches the loaded values before the accumulate step: a load behind a lane mask or a
+    // branch is compiled into branch + load + wait, i.e. one memory round trip per posting (this loop used to spend
+    // 16 us per workgroup that way), and it makes the number of loads in flight unknown where the paths join.
     auto fetch = [&](u64 i0, u64 b, u32 (&d)[U], float (&im)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {   // eight independent 1 KiB-per-instruction loads of each stream
             const u64 i = i0 + (u64)j * 256 + tid;
-            const bool ok = i < b;
-            d[j] = ok ? doc_ids[i] - tlo : 0xFFFFFFFFu;
-            im[j] = ok ? impacts[i] : 0.f;
+            const u64 ic = i < b ? i : 0;
+            d[j] = doc_ids[ic];
+            im[j] = impacts[ic];
         }
     };
     int cs = 0;              // cursor: next chunk to fetch = [cpos, ..) of slot cs
     u64 cpos = ns > 0 ? ra[0] : 0;
     auto next_chunk = [&](int& slot, u64& pos, u64& bound) -> bool {
         while (cs < ns && cpos >= rb[cs]) { ++cs; if (cs < ns) cpos = ra[cs]; }
-        if (cs >= ns) return false;
+        if (cs >= ns) { pos = 0; bound = 0; return false; }
         slot = cs; pos = cpos; bound = rb[cs];
         cpos += CH;
         return true;
     };
-    u32 dA[U], dB[U];
-    float mA[U], mB[U];
-    int sA = 0, sB = 0;
-    u64 pA = 0, pB = 0, bA = 0, bB = 0;
-    bool haveA = next_chunk(sA, pA, bA);
-    if (haveA) fetch(pA, bA, dA, mA);
-    while (haveA) {
-        const bool haveB = next_chunk(sB, pB, bB);
-        if (haveB) fetch(pB, bB, dB, mB);
+    // D chunks in flight (a tile's share of a list is usually one or two chunks, so this is "the next slots are already
+    // on their way")
+    constexpr int D = 4;
+    u32 dR[D][U];
+    float mR[D][U];
+    int sR[D];
+    bool hR[D];
+    u64 pR[D], bR[D];
 #pragma unroll
-        for (int j = 0; j < U; ++j)
-            if (dA[j] < tlen) tacc[dA[j]] += mA[j];
-        if (!haveB || sB != sA) __syncthreads();   // slot boundary: later slots add to the same documents
+    for (int r = 0; r < D; ++r) {
+        sR[r] = 0;
+        hR[r] = next_chunk(sR[r], pR[r], bR[r]);
+        fetch(pR[r], bR[r], dR[r], mR[r]);
+    }
+    while (hR[0]) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) { dA[j] = dB[j]; mA[j] = mB[j]; }
-        sA = sB; pA = pB; bA = bB;
-        haveA = haveB;
+        for (int r = 0; r < D; ++r) {
+            if (!hR[r]) break;   // chunks are handed out in order: the first empty ring entry ends the stream
+            // a chunk lies inside one list, so its documents are distinct: read all eight accumulators, then write
+            // them (as `+=` the compiler must assume aliasing and runs eight dependent LDS round trips)
+            u32 dd[U];
+            float cur[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const u32 x = dR[r][j] - tlo;
+                dd[j] = (pR[r] + (u64)j * 256 + tid < bR[r] && x < tlen) ? x : 0xFFFFFFFFu;
+                cur[j] = tacc[dd[j] != 0xFFFFFFFFu ? dd[j] : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (dd[j] != 0xFFFFFFFFu) tacc[dd[j]] = cur[j] + mR[r][j];
+            const int nr = (r + 1) % D;              // the chunk that follows in stream order (static after unrolling)
+            const bool boundary = !hR[nr] || sR[nr] != sR[r];
+            hR[r] = next_chunk(sR[r], pR[r], bR[r]); // re-arm this entry before the barrier: its loads fly through it
+            fetch(pR[r], bR[r], dR[r], mR[r]);
+            if (boundary) __syncthreads();           // slot boundary: later slots add to the same documents
+        }
     }
     __syncthreads();
     if (dp && tid == 0) dp[2] = wall_clock64();
