@@ -782,15 +782,17 @@ __device__ __forceinline__ double rescore4(const float4* __restrict__ xb, int P,
     const float4* src = xb + blk * P * kPieceVec4 + hh * 32 + r0 + rr;
     // P <= 128 (LDS limit of the scan), so a lane touches at most 16 pieces.  Loads go out in batches of 8 before their
     // first use: a dependent-latency loop here costs an HBM round trip per piece and used to dominate the finish kernel;
-    // all 16 at once spills at the 128-VGPR budget of the 16-wave finish workgroup.
+    // all 16 at once spills at the 128-VGPR budget of the 16-wave finish workgroup.  (P >= 1: d >= 1.)
     double acc = 0.0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float4 x[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int p = pq + 8 * (8 * half + i);
-            x[i] = p < P ? src[p * kPieceVec4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // UNCONDITIONAL load (pieces past P re-read the last one and are skipped below): `p < P ? src[..] : 0` is
+            // compiled into branch + load + s_waitcnt vmcnt(0), i.e. sixteen serialized memory round trips per quad
+            const int p = min(pq + 8 * (8 * half + i), P - 1);
+            x[i] = src[p * kPieceVec4];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1011,6 +1013,7 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     if (a.dbg && tid == 0) atomicMin(a.dbg + 1, (unsigned long long)wall_clock64());
 
     double qpart = 0.0, dpart = 0.0;
+#pragma unroll 4
     for (int c = tid; c < a.d; c += NT) {
         const float vf = a.q[(int64_t)q * a.d + c];
         const double v = (double)vf, dv = v - (double)(float)(__bf16)vf;   // the scan's query tile holds bf16(q), RNE
@@ -1021,15 +1024,20 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
     for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
     const u64* sk = a.ck + (int64_t)q * a.ncand;
     const i64* si = a.ci + (int64_t)q * a.ncand;
+    // unconditional loads of keys AND slots (clamped index), combined afterwards: behind `if (i < ncand)` / `if (kk)`
+    // every candidate cost two dependent, serialized memory round trips
     u64 c[NPL];
+    i64 cs[NPL];
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+        const int64_t i = min(((int64_t)wave * NPL + n) * 64 + lane, a.ncand - 1);
+        c[n] = sk[i];
+        cs[n] = si[i];
+    }
 #pragma unroll
     for (int n = 0; n < NPL; ++n) {
         const int64_t i = ((int64_t)wave * NPL + n) * 64 + lane;
-        c[n] = 0;
-        if (i < a.ncand) {
-            const u64 kk = sk[i];
-            if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
-        }
+        c[n] = (i < a.ncand && c[n] != 0) ? (c[n] | (u64)(0xFFFFFFFFu - (u32)cs[n])) : 0;
     }
     WaveListPacked L;
     wave_topk_packed<NPL>(c, K1, L);
@@ -1226,17 +1234,21 @@ __global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
     const float tau = a.tau[q];
     const float* src = a.gmax + (int64_t)q * a.gstride;
     const int64_t base = (int64_t)blockIdx.x * 4096 + threadIdx.x * 4;
+    // all four loads first (unconditional; the row of gmax is padded to gstride >= ngroups rounded up to 4 -- past
+    // ngroups the values are masked below), then the rare appends
+    float4 xs[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t i = min(base + it * 1024, (int64_t)(max((int64_t)0, a.ngroups - 1) & ~3ll));
+        xs[it] = *reinterpret_cast<const float4*>(src + i);
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int64_t i = base + it * 1024;
-        float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (i + 3 < a.ngroups) {
-            const float4 x = *reinterpret_cast<const float4*>(src + i);
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        } else {
-            for (int t = 0; t < 4; ++t)
-                if (i + t < a.ngroups) v[t] = src[i + t];
-        }
+        float v[4] = {xs[it].x, xs[it].y, xs[it].z, xs[it].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (i + t >= a.ngroups) v[t] = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             if (v[t] >= tau && v[t] > -1.0e38f) {

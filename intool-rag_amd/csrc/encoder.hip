@@ -383,26 +383,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= M) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * H);
     const int nv = H >> 8;  // float4 per lane (H is a multiple of 128; a 128-wide remainder is handled by half the lanes)
-    float4 v[8];
+    float4 v[8], gm[8], bt[8];
     float s = 0.f;
     const int nvec = H >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    // every load of the row's working set is issued up front and UNCONDITIONALLY (clamped column): a load under a lane
+    // mask is compiled into branch + load + wait, one memory round trip each
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cc = min(i * 64 + lane, nvec - 1);
+        gm[i] = g4[cc];
+        bt[i] = b4[cc];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = i * 64 + lane;
-        v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PARTS && c < nvec) {
-#pragma unroll
-            for (int sp = 1; sp < 4; ++sp) {
-                if (sp < nsplit) {
-                    const float4 p = xr[(size_t)sp * M * (H >> 2) + c];
-                    v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
-                }
-            }
+        v[i] = xr[min(c, nvec - 1)];
+        if (c >= nvec) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PARTS) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4r;
-            const float4 b = reinterpret_cast<const float4*>(bias)[c];
-            const bf16x4r rs = reinterpret_cast<const bf16x4r*>(resid + (size_t)row * H)[c];
-            v[i].x = (v[i].x + b.x) + (float)rs[0]; v[i].y = (v[i].y + b.y) + (float)rs[1];
-            v[i].z = (v[i].z + b.z) + (float)rs[2]; v[i].w = (v[i].w + b.w) + (float)rs[3];
+            const int cc = min(c, nvec - 1);
+            float4 p[3];
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp) p[sp - 1] = xr[(size_t)min(sp, nsplit - 1) * M * (H >> 2) + cc];
+            const float4 b = reinterpret_cast<const float4*>(bias)[cc];
+            const bf16x4r rs = reinterpret_cast<const bf16x4r*>(resid + (size_t)row * H)[cc];
+            if (c < nvec) {
+#pragma unroll
+                for (int sp = 1; sp < 4; ++sp)
+                    if (sp < nsplit) { v[i].x += p[sp - 1].x; v[i].y += p[sp - 1].y; v[i].z += p[sp - 1].z; v[i].w += p[sp - 1].w; }
+                v[i].x = (v[i].x + b.x) + (float)rs[0]; v[i].y = (v[i].y + b.y) + (float)rs[1];
+                v[i].z = (v[i].z + b.z) + (float)rs[2]; v[i].w = (v[i].w + b.w) + (float)rs[3];
+            }
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -420,13 +433,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * H);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = i * 64 + lane;
         if (c < nvec) {
-            const float4 g = g4[c], b = b4[c];
+            const float4 g = gm[i], b = bt[i];
             bf16x4 o;
             o[0] = (bf16)((v[i].x - mean) * rstd * g.x + b.x);
             o[1] = (bf16)((v[i].y - mean) * rstd * g.y + b.y);

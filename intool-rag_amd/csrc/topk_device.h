@@ -409,15 +409,20 @@ __global__ __launch_bounds__(1024) void merge_packed_kernel(const u64* __restric
     const u64* sk = ck + (i64)q * ncand;
     const i64* si = ci + (i64)q * ncand;
     {
+        // unconditional loads of keys and ids (clamped index), combined afterwards: behind `if (i < ncand)` / `if (kk)`
+        // every candidate cost two dependent, serialized memory round trips (32 of them at NPL = 16)
         u64 c[NPL];
+        i64 cs[NPL];
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const i64 i = min(((i64)wave * NPL + n) * 64 + lane, ncand - 1);
+            c[n] = sk[i];
+            cs[n] = si[i];
+        }
 #pragma unroll
         for (int n = 0; n < NPL; ++n) {
             const i64 i = ((i64)wave * NPL + n) * 64 + lane;
-            c[n] = 0;
-            if (i < ncand) {
-                const u64 kk = sk[i];
-                if (kk != 0) c[n] = kk | (u64)(0xFFFFFFFFu - (u32)si[i]);
-            }
+            c[n] = (i < ncand && c[n] != 0) ? (c[n] | (u64)(0xFFFFFFFFu - (u32)cs[n])) : 0;
         }
         WaveListPacked L;
         wave_topk_packed<NPL>(c, k, L);
