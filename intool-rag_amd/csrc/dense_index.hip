@@ -105,24 +105,42 @@ __global__ void untile_kernel(const float4* __restrict__ xb, int64_t row0, int64
     if (col + 3 < d) o[3] = v.w;
 }
 
-// one wave per row: fp64 sum of squares -> float; running max of squared norm (float bits, non-negative)
-__global__ void norms_kernel(const float* __restrict__ src, int64_t row0, int64_t n, int d, float* __restrict__ norms,
-                             unsigned* __restrict__ max_norm2_bits)
+// Row statistics of one add: |x|^2 (fp64 sum -> float, stored per row; its running maximum rounded UP) and
+// |x - bf16(x)|^2 (running maximum, rounded up: the certificate of the bf16 scan bounds |<x - x^, q^>| by |x - x^| |q^|).
+// One wave per row at a time, rows grid-strided, each row read ONCE for both sums; a wave keeps its maxima in registers
+// and issues two atomics when it is done (one atomicMax per ROW on a single address serialised 125 k of them per
+// 125 k-row add: 1.4 ms for a kernel that reads 512 MB).
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ src, int64_t row0, int64_t n, int d,
+                                                        float* __restrict__ norms, unsigned* __restrict__ max_norm2_bits,
+                                                        unsigned* __restrict__ max_dx2_bits)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* s = src + row * (int64_t)d;
-    double acc = 0.0;
-    for (int c = lane; c < d; c += 64) { double v = (double)s[c]; acc += v * v; }
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float mx_n = 0.f, mx_d = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < n; row += nw) {
+        const float* s = src + row * (int64_t)d;
+        double acc = 0.0, dcc = 0.0;
+#pragma unroll 8
+        for (int c = lane; c < d; c += 64) {
+            const float f = s[c];
+            const double v = (double)f, dv = v - (double)(float)(__bf16)f;
+            acc += v * v;
+            dcc += dv * dv;
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) {
+        for (int off = 32; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); dcc += __shfl_xor(dcc, off); }
         float f = (float)acc;
-        norms[row0 + row] = f;
-        // round up so the stored maximum is an upper bound of the exact value
-        float up = (double)f < acc ? nextafterf(f, INFINITY) : f;
-        atomicMax(max_norm2_bits, __float_as_uint(up));
+        if (lane == 0) norms[row0 + row] = f;
+        // round up so the stored maxima are upper bounds of the exact values
+        if ((double)f < acc) f = nextafterf(f, INFINITY);
+        float g = (float)dcc;
+        if ((double)g < dcc) g = nextafterf(g, INFINITY);
+        mx_n = fmaxf(mx_n, f);
+        mx_d = fmaxf(mx_d, g);
+    }
+    if (lane == 0) {
+        atomicMax(max_norm2_bits, __float_as_uint(mx_n));
+        atomicMax(max_dx2_bits, __float_as_uint(mx_d));
     }
 }
 
@@ -151,25 +169,6 @@ __global__ void retile_bf16_kernel(const float* __restrict__ src, int64_t row0, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (__bf16)(col + j < d ? s[j] : 0.f);
     xh[(blk * P2 + p) * 64 + lane] = v;
-}
-
-// one wave per row: |x - bf16(x)|^2 in fp64, running maximum (float bits, rounded up) -- the certificate of the bf16
-// scan bounds |<x - x^, q^>| by |x - x^| |q^|
-__global__ void trunc_norms_kernel(const float* __restrict__ src, int64_t n, int d, unsigned* __restrict__ max_dx2_bits)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* s = src + row * (int64_t)d;
-    double acc = 0.0;
-    for (int c = lane; c < d; c += 64) { const double dv = (double)s[c] - (double)(float)(__bf16)s[c]; acc += dv * dv; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) {
-        float f = (float)acc;
-        if ((double)f < acc) f = nextafterf(f, INFINITY);
-        atomicMax(max_dx2_bits, __float_as_uint(f));
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1583,11 +1582,10 @@ struct DenseIndex {
         const int64_t threads = nblk * P * kPieceVec4;
         hipLaunchKernelGGL(retile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x_dev, ntotal, n, d, P,
                            xb.as<float4>());
-        hipLaunchKernelGGL(norms_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x_dev, ntotal, n, d,
-                           norms.as<float>(), max_norm2_bits());
+        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 4096)), dim3(256), 0, st, x_dev,
+                           ntotal, n, d, norms.as<float>(), max_norm2_bits(), max_dx2_bits());
         hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((nblk * (P / 2) * 64 + 255) / 256)), dim3(256), 0, st, x_dev, ntotal, n,
                            d, P / 2, xh.as<bf16x8_t>());
-        hipLaunchKernelGGL(trunc_norms_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x_dev, n, d, max_dx2_bits());
         HR_CHECK_HIP(hipGetLastError());
         ntotal += n;
         update_launch_q();
