@@ -166,8 +166,14 @@ __global__ void retile_bf16_kernel(const float* __restrict__ src, int64_t row0, 
     const int col = 16 * p + 8 * h;
     const float* s = src + (row - row0) * (int64_t)d + col;
     bf16x8_t v;
+    if ((d & 3) == 0 && col + 8 <= d) {   // the usual case: two 16-B loads (eight predicated scalar loads cost a round trip each)
+        const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(col + j < d ? s[j] : 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)(col + j < d ? s[j] : 0.f);
+    }
     xh[(blk * P2 + p) * 64 + lane] = v;
 }
 

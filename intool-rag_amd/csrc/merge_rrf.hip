@@ -65,18 +65,22 @@ __global__ __launch_bounds__(64) void merge_wave_kernel(const double* __restrict
     u64 ck[NPL];
     i64 ci[NPL];
     u64 m = 0;
+    // unconditional loads with a clamped index, then the masking: behind `if (i < M)` each candidate is a branch + two
+    // loads + s_waitcnt vmcnt(0), one memory round trip per candidate on the tail of every multi-GPU step
+    double cs[NPL];
 #pragma unroll
     for (int n = 0; n < NPL; ++n) {
-        const int i = n * 64 + lane;
-        ck[n] = 0;
-        ci[n] = -1;
-        if (i < M) {
-            const int part = i / k_in, j = i % k_in;
-            const i64 o = (i64)part * part_stride + (i64)q * k_in + j;
-            ci[n] = in_i[o];
-            const double s = in_s[o];
-            ck[n] = ci[n] < 0 ? 0ull : ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
-        }
+        const int i = min(n * 64 + lane, M - 1);
+        const int part = i / k_in, j = i % k_in;
+        const i64 o = (i64)part * part_stride + (i64)q * k_in + j;
+        ci[n] = in_i[o];
+        cs[n] = in_s[o];
+    }
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+        const bool ok = n * 64 + lane < M && ci[n] >= 0;
+        ck[n] = ok ? ord64(METRIC == HIPRAG_METRIC_IP ? cs[n] : -cs[n]) : 0ull;
+        if (!ok) ci[n] = -1;
         m = ck[n] > m ? ck[n] : m;
     }
     const u64 t0 = wave_kth_of_lanes(m, k_out);
