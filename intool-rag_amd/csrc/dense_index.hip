@@ -697,7 +697,45 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
         {
             bf16x8* qw = reinterpret_cast<bf16x8*>(qs);
             const bool vec_ok = (a.d & 3) == 0;
-            for (int idx = tid; idx < 2 * P2 * 64; idx += NT) {
+            int idx0 = tid;
+            if (vec_ok && a.d >= 4) {
+                // four fragments per step, their eight 16-B loads issued together and UNCONDITIONALLY (clamped query and
+                // column, masked afterwards): predicated, each load was a branch + load + s_waitcnt vmcnt(0) -- 32
+                // dependent L2 round trips per thread and pass
+                constexpr int UQ = 4;
+                for (; idx0 + (UQ - 1) * NT < 2 * P2 * 64; idx0 += UQ * NT) {
+                    float4 t0[UQ], t1[UQ];
+#pragma unroll
+                    for (int u4 = 0; u4 < UQ; ++u4) {
+                        const int idx = idx0 + u4 * NT;
+                        const int tile = idx >= P2 * 64;
+                        const int u = idx - tile * P2 * 64;
+                        const int p = u >> 6, l = u & 63;
+                        const int b = min(qbase + (l & 31) + 32 * tile, a.nq - 1);
+                        const int col = 16 * p + 8 * (l >> 5);
+                        const float* qp = a.q + (int64_t)b * a.d;
+                        t0[u4] = *reinterpret_cast<const float4*>(qp + min(col, a.d - 4));
+                        t1[u4] = *reinterpret_cast<const float4*>(qp + min(col + 4, a.d - 4));
+                    }
+#pragma unroll
+                    for (int u4 = 0; u4 < UQ; ++u4) {
+                        const int idx = idx0 + u4 * NT;
+                        const int tile = idx >= P2 * 64;
+                        const int u = idx - tile * P2 * 64;
+                        const int p = u >> 6, l = u & 63;
+                        const int b = qbase + (l & 31) + 32 * tile;
+                        const int col = 16 * p + 8 * (l >> 5);
+                        const bool ok0 = b < a.nq && col + 3 < a.d, ok1 = b < a.nq && col + 7 < a.d;
+                        bf16x8 o;
+                        o[0] = (__bf16)(ok0 ? t0[u4].x : 0.f); o[1] = (__bf16)(ok0 ? t0[u4].y : 0.f);
+                        o[2] = (__bf16)(ok0 ? t0[u4].z : 0.f); o[3] = (__bf16)(ok0 ? t0[u4].w : 0.f);
+                        o[4] = (__bf16)(ok1 ? t1[u4].x : 0.f); o[5] = (__bf16)(ok1 ? t1[u4].y : 0.f);
+                        o[6] = (__bf16)(ok1 ? t1[u4].z : 0.f); o[7] = (__bf16)(ok1 ? t1[u4].w : 0.f);
+                        qw[idx] = o;
+                    }
+                }
+            }
+            for (int idx = idx0; idx < 2 * P2 * 64; idx += NT) {
                 const int tile = idx >= P2 * 64;
                 const int u = idx - tile * P2 * 64;
                 const int p = u >> 6, l = u & 63;
