@@ -184,11 +184,11 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     __syncthreads();
     if (dp && tid == 0) dp[2] = wall_clock64();
     // ---- tile top-K1 out of LDS: wave w filters accumulators [4096 w, 4096 (w + 1)) like select_wave_kernel<true> ----
-    constexpr int NV = 16;
+    constexpr int NV = kTileDocs / 1024;   // float4 per lane: a wave filters a quarter of the tile
     float v[NV * 4];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-        const float4 x = reinterpret_cast<const float4*>(tacc)[wv * 1024 + it * 64 + lane];
+        const float4 x = reinterpret_cast<const float4*>(tacc)[wv * (kTileDocs / 16) + it * 64 + lane];
         v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
     }
     float m = -INFINITY;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     u64 tau = best ? ((u64)best << 32) - 1 : 0;
 #pragma unroll
     for (int n = 0; n < NV * 4; ++n) {
-        const u32 local = (u32)wv * 4096u + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+        const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
         u64 c = 0;
         if (v[n] > 0.f && local < tlen) c = pack_key(v[n], tlo + local);
         tau = L.offer(c, K1, tau);
