@@ -159,32 +159,42 @@ class HipEncoder:
             ids[i, :len(t)] = np.asarray(t, dtype=np.int32)
         return ids, lens, max_len
 
-    def _run(self, fn: str, token_lists: Sequence[Sequence[int]], out_cols: int, batch_size: int):
+    def _run(self, fn: str, token_lists: Sequence[Sequence[int]], out_cols: int, batch_size: int,
+             max_tokens: Optional[int] = None):
         """Length-sorted batches (what sentence-transformers' encode does with batch_size=32); results are restored
-        to input order and do not depend on the batching: padding never reaches a real token."""
+        to input order and do not depend on the batching: padding never reaches a real token.
+        `max_tokens`: form batches by PADDED TOKEN COUNT instead of sequence count -- as many of the next-longest
+        sequences as fit nseq * S <= max_tokens (S = the batch's longest, rounded up to 64) and nseq <= batch_size; short
+        texts then fill the GPU as well as long ones do (32 x 128 tokens is a twentieth of what one forward can take)."""
         import torch
         from .index import _stream_ptr
         n = len(token_lists)
         shape = (n, out_cols) if out_cols > 1 else (n,)
         out = torch.zeros(shape, dtype=torch.float32, device=torch.device("cuda", self.device))
         order = sorted(range(n), key=lambda i: -len(token_lists[i]))
-        for o in range(0, n, batch_size):
-            idx = order[o:o + batch_size]
+        o = 0
+        while o < n:
+            take = batch_size
+            if max_tokens is not None:
+                s_pad = max(64, -(-len(token_lists[order[o]]) // 64) * 64)
+                take = max(1, min(batch_size, max_tokens // s_pad))
+            idx = order[o:o + take]
+            o += take
             ids, lens, max_len = self._pad([token_lists[i] for i in idx])
             part = torch.empty((len(idx), out_cols) if out_cols > 1 else (len(idx),), dtype=torch.float32, device=out.device)
             nat.call(fn, self._h, ids.ctypes.data, lens.ctypes.data, len(idx), max_len, part.data_ptr(), _stream_ptr())
             out[torch.as_tensor(idx, device=out.device)] = part
         return out
 
-    def encode_tokens(self, token_lists: Sequence[Sequence[int]], batch_size: int = 256):
+    def encode_tokens(self, token_lists: Sequence[Sequence[int]], batch_size: int = 256, max_tokens: Optional[int] = None):
         """-> float32 CUDA tensor [n, hidden]: L2-normalised CLS embeddings (zero rows for empty token lists)."""
-        return self._run("hipenc_forward", token_lists, self.cfg.hidden, batch_size)
+        return self._run("hipenc_forward", token_lists, self.cfg.hidden, batch_size, max_tokens)
 
-    def score_tokens(self, token_lists: Sequence[Sequence[int]], batch_size: int = 64):
+    def score_tokens(self, token_lists: Sequence[Sequence[int]], batch_size: int = 64, max_tokens: Optional[int] = None):
         """-> float32 CUDA tensor [n]: classification-head logits of `<s> query </s></s> passage </s>` sequences."""
         if not self.has_head:
             raise ValueError("this encoder was created without a classification head")
-        return self._run("hipenc_score_pairs", token_lists, 1, batch_size)
+        return self._run("hipenc_score_pairs", token_lists, 1, batch_size, max_tokens)
 
     def last_flops(self) -> float:
         v = ctypes.c_double()

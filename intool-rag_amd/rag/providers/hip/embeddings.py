@@ -36,6 +36,13 @@ except Exception as _e:
     _ERR = _e
 
 
+# One forward takes up to this many padded tokens (the BASELINE config-5 batch, 256 x 512): batches are cut by token count,
+# not by sequence count, so that short chunks fill the GPU as well as long ones (sentence-transformers' 32 sequences of
+# ~128 tokens are a twentieth of it).  EMBEDDING_BATCH_SIZE is accepted and ignored like in the reference (:64-65).
+_MAX_BATCH_TOKENS = int(os.getenv("HIP_ENCODER_BATCH_TOKENS", str(256 * 512)))
+_MAX_BATCH_SEQS = 4096
+
+
 def _encoder_config() -> "EncoderConfig":
     cfg = EncoderConfig()                                  # XLM-R large = BAAI/bge-m3 (config.EMBEDDING_MODEL)
     override = os.getenv("HIP_ENCODER_CONFIG")             # JSON, e.g. {"layers": 2, "hidden": 256, ...} for tests
@@ -70,7 +77,7 @@ class HipEmbeddingProvider(EmbeddingProvider):
     def _encode(self, texts: List[str]) -> List[List[float]]:
         toks = [self.tokenizer.encode(t.replace("\n", " "), self.encoder.cfg.max_seq_len) for t in texts]
         with self._lock:
-            out = self.encoder.encode_tokens(toks, batch_size=max(32, config.EMBEDDING_BATCH_SIZE))
+            out = self.encoder.encode_tokens(toks, batch_size=_MAX_BATCH_SEQS, max_tokens=_MAX_BATCH_TOKENS)
             return out.cpu().tolist()
 
     async def embed_single(self, text: str, instruction: Optional[str] = None) -> List[float]:
@@ -106,7 +113,7 @@ class HipEmbeddingProvider(EmbeddingProvider):
         def run():
             toks = [self.tokenizer.encode(t.replace("\n", " "), self.encoder.cfg.max_seq_len) for t in clean_texts]
             with self._lock:
-                return self.encoder.encode_tokens(toks, batch_size=max(32, config.EMBEDDING_BATCH_SIZE))
+                return self.encoder.encode_tokens(toks, batch_size=_MAX_BATCH_SEQS, max_tokens=_MAX_BATCH_TOKENS)
         return await asyncio.to_thread(run)
 
     def dimension(self) -> int:

@@ -21,11 +21,17 @@ class HashTokenizer:
 
     def __init__(self, vocab: int, bos: int = 0, eos: int = 2, first_id: int = 3):
         self.vocab, self.bos, self.eos, self.first = vocab, bos, eos, first_id
+        self._memo = {}
         logger.warning("[EMBED] no tokenizer file (HIP_TOKENIZER_FILE): using the SYNTHETIC hashing tokenizer")
 
     def _id(self, tok: str) -> int:
-        h = int.from_bytes(hashlib.blake2b(tok.encode("utf-8"), digest_size=8).digest(), "little")
-        return self.first + h % (self.vocab - self.first)
+        hit = self._memo.get(tok)
+        if hit is None:
+            h = int.from_bytes(hashlib.blake2b(tok.encode("utf-8"), digest_size=8).digest(), "little")
+            hit = self.first + h % (self.vocab - self.first)
+            if len(self._memo) < 1_000_000:
+                self._memo[tok] = hit
+        return hit
 
     def encode(self, text: str, max_len: int) -> List[int]:
         body = [self._id(t) for t in text.lower().split()][:max(0, max_len - 2)]

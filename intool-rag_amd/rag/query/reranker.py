@@ -51,7 +51,7 @@ class CrossEncoderReranker:
         pairs = [self.tokenizer.encode_pair(query.replace("\n", " "), p.replace("\n", " "), self.encoder.cfg.max_seq_len)
                  for p in passages]
         with self._lock:
-            return self.encoder.score_tokens(pairs).cpu().tolist()
+            return self.encoder.score_tokens(pairs, batch_size=4096, max_tokens=256 * 512).cpu().tolist()
 
     async def rerank(self, query: str, chunks: list, top_k: Optional[int] = None) -> list:
         """chunks: RetrievedChunk list in retrieval order -> the top_k by cross-encoder logit; each returned chunk carries
