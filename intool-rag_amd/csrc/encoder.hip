@@ -390,17 +390,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float4* b4 = reinterpret_cast<const float4*>(beta);
     // every load of the row's working set is issued up front and UNCONDITIONALLY (clamped column): a load under a lane
     // mask is compiled into branch + load + wait, one memory round trip each
+    if (PARTS) {   // latency path only: the batch path is bandwidth-bound and better off with fewer live registers
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int cc = min(i * 64 + lane, nvec - 1);
-        gm[i] = g4[cc];
-        bt[i] = b4[cc];
+        for (int i = 0; i < 8; ++i) {
+            const int cc = min(i * 64 + lane, nvec - 1);
+            gm[i] = g4[cc];
+            bt[i] = b4[cc];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = i * 64 + lane;
-        v[i] = xr[min(c, nvec - 1)];
-        if (c >= nvec) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PARTS) {
+            v[i] = xr[min(c, nvec - 1)];
+            if (c >= nvec) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (PARTS) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4r;
             const int cc = min(c, nvec - 1);
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < 8; ++i) {
         const int c = i * 64 + lane;
         if (c < nvec) {
-            const float4 g = gm[i], b = bt[i];
+            const float4 g = PARTS ? gm[i] : g4[c], b = PARTS ? bt[i] : b4[c];
             bf16x4 o;
             o[0] = (bf16)((v[i].x - mean) * rstd * g.x + b.x);
             o[1] = (bf16)((v[i].y - mean) * rstd * g.y + b.y);
