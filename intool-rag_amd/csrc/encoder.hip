@@ -42,7 +42,7 @@ constexpr int kGemmThreads = 256;
 
 __device__ __forceinline__ int swz_unit(int kc, int row, int rows) { return kc * rows + (row ^ (kc & 7)); }
 
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PART = 3 };
 
 struct GemmArgs {
     const bf16* A;      // [M, K] row-major
@@ -59,6 +59,8 @@ struct GemmArgs {
     // EPI_RESID
     const bf16* resid;  // [M, N]
     float* out_f32;     // [M, N]
+    // EPI_PART: raw fp32 partial products [ksplit][M][N] (K split over workgroups; the LayerNorm that follows adds them)
+    int ksplit;
 };
 
 // erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): far below the bf16 resolution of the value it feeds, and a third of
@@ -94,9 +96,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
     // XCD-aware block mapping: consecutive block ids go round-robin over the 8 XCDs, so give each XCD a contiguous range
     // of tiles; inside it the N index runs fastest, i.e. the blocks sharing an A row-panel share one L2.
     const int nbn = g.N / BN;
-    const int nblk = gridDim.x;
+    const int ksplit = EPI == EPI_PART ? g.ksplit : 1;
+    const int nblk = gridDim.x / ksplit;
+    const int split = blockIdx.x / nblk, bid = blockIdx.x - split * nblk;
     const int per = nblk >> 3, rem = nblk & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bid & 7, idx = bid >> 3;
     const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
     // tile order inside an XCD's range: groups of 8 column tiles, row tiles fastest inside a group -- the group's weight
     // tiles (1024 rows of W = 2 MB at K = 1024) stay L2-resident while the activations stream past them (3 % over
@@ -128,13 +132,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
         }
     };
 
-    const int nk = g.K / BK;
-    stage(0, 0);
+    const int nk = g.K / ksplit / BK;
+    const int kbeg = split * (g.K / ksplit);
+    stage(0, kbeg);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
         __syncthreads();                                   // ... everyone's has, and buffer buf^1 is no longer being read
-        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);    // DMA of the next tile flies under this tile's MFMAs
+        if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);    // DMA of the next tile flies under this tile's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -188,6 +193,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
         if (m >= g.M) continue;
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * BN + cg * 8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * BN + cg * 8 + 4);
+        if (EPI == EPI_PART) {
+            float* dst = g.out_f32 + ((size_t)split * g.M + m) * g.N + n;
+            *reinterpret_cast<float4*>(dst) = c0;
+            *reinterpret_cast<float4*>(dst + 4) = c1;
+            continue;
+        }
         const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n);
         const float4 b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
         float x[8] = {c0.x + b0.x, c0.y + b0.y, c0.z + b0.z, c0.w + b0.w, c1.x + b1.x, c1.y + b1.y, c1.z + b1.z, c1.w + b1.w};
@@ -228,7 +239,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
 // (ksplit = K / Kc) which write raw fp32 partials [ksplit][M][N]; the LayerNorm that follows adds them up in split order,
 // so there are no atomics and results do not depend on scheduling.
 // ---------------------------------------------------------------------------------------------------------
-enum { EPI_PART = 3 };
 constexpr int SK_STEPS = 8;   // 32-deep MFMA steps per wave (K range per workgroup <= 4 * 8 * 32 = 1024)
 
 // NT: 16-column tiles per wave (the workgroup owns 16 * NT output columns; NT = 2 halves the L2 reads of A, which every
@@ -729,7 +739,16 @@ struct Encoder {
         // one query / a few short texts: weight-streaming GEMMs instead of 128 x 128 tiles (S is a multiple of 64, so is T)
         const bool small = small_rows > 0 && T <= small_rows && H <= 1024 && skinny_ok(H) && skinny_ok(F) && skinny_split(F) <= 4;
         const int fsplit = skinny_split(F);
-        if ((rc = pre.reserve((size_t)M * H * 4 * (small ? fsplit : 1)))) return rc;
+        // tiled path, N = H products (out-proj, F -> H): with few row tiles their (H/128) x (M/128) workgroups leave most
+        // CUs idle while each walks K serially (F -> H at 2560 rows: 160 workgroups x 64 k-tiles = 64 us of a 165 us
+        // layer) -- split K until the launch has ~512 workgroups; the LayerNorm sums the partials
+        auto tile_split = [&](int K) {
+            int ks = 1;
+            while (ks < 4 && (H / BN) * (M / BM) * ks < 512 && K % (ks * 2 * BK) == 0 && K / (ks * 2) >= 256) ks *= 2;
+            return ks;
+        };
+        const int osplit = small ? 1 : tile_split(H), dsplit = small ? 1 : tile_split(F);
+        if ((rc = pre.reserve((size_t)M * H * 4 * (small ? fsplit : std::max(osplit, dsplit))))) return rc;
         if ((rc = ffn.reserve((size_t)M * F * 2))) return rc;
         // host staging: pad token rows to S with pad_id
         std::vector<int32_t> tp((size_t)nseq * S, cfg.pad_id);
@@ -771,6 +790,12 @@ struct Encoder {
                 hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                    (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), T, H, cfg.ln_eps, skinny_split(H),
                                    (const float*)L.bo, X);
+            } else if (osplit > 1) {
+                o.ksplit = osplit;
+                hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * osplit), dim3(kGemmThreads), 0, st, o);
+                hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps, osplit,
+                                   (const float*)L.bo, X);
             } else {
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, o);
                 hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
@@ -790,6 +815,12 @@ struct Encoder {
                 launch_skinny<EPI_PART>(f2, st);
                 hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                    (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), T, H, cfg.ln_eps, fsplit,
+                                   (const float*)L.b2, X);
+            } else if (dsplit > 1) {
+                f2.ksplit = dsplit;
+                hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * dsplit), dim3(kGemmThreads), 0, st, f2);
+                hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps, dsplit,
                                    (const float*)L.b2, X);
             } else {
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, dim3((H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f2);
