@@ -174,7 +174,7 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
  * torch.nn.Linear layout [out, in]; biases and LayerNorm parameters fp32.  Token ids / lengths are HOST arrays
  * ([nseq, max_len] int32, right-padded; lengths include BOS/EOS).  Outputs are DEVICE fp32: forward -> [nseq, hidden]
  * L2-normalised CLS embeddings (zeros for length-0 rows); score_pairs -> [nseq] logits.
- * Batches of at most HIPENC_SMALL_ROWS (environment, read at create; default 512, 0 = never) padded token rows -- one
+ * Batches of at most HIPENC_SMALL_ROWS (environment, read at create; default 384, 0 = never) padded token rows -- one
  * query through embed_single, a few short texts -- run the GEMMs as weight-streaming workgroups instead of 128 x 128
  * tiles (1.3 ms instead of 3.3 ms for one query on the 24-layer model); same arithmetic, fixed summation order. */
 typedef struct hipenc_config {

@@ -15,7 +15,7 @@
 //   K6/K8/K9 gemm_bf16_kernel 128x128x64 LDS-tiled GEMM, C = A[M,K] * W[N,K]^T, fused epilogues:
 //            QKV (bias, 1/8 scale on q, head-major q/k and TRANSPOSED v), GELU (bias + erf-GELU), RESID (bias + residual
 //            -> fp32 pre-LayerNorm buffer)
-//            gemm_skinny_kernel: the same products for <= 512 token rows (one query, a few short texts) as
+//            gemm_skinny_kernel: the same products for <= 384 token rows (one query, a few short texts) as
 //            weight-streaming workgroups of 16/32 columns; split-K partials are summed by the LayerNorm
 //   K7  attention_kernel     flash-style, computed transposed: 128 queries x 64-key tiles, online softmax in fp32, P stays in registers
 //       layernorm_kernel     fp32 pre-LN rows -> bf16
@@ -695,8 +695,9 @@ struct Encoder {
     std::vector<hipenc_layer_weights> layers;
     DevBuf tokens, lens, x, q, k, vt, ctx, pre, ffn, pooled;
     double flops_last = 0.0;
-    int small_rows = 512;    // batches of at most this many (padded) token rows take the small-batch GEMM; 0 = never
-                             // (HIPENC_SMALL_ROWS; measured crossover with the tiled GEMM ~1024 rows)
+    int small_rows = 384;    // batches of at most this many (padded) token rows take the small-batch GEMM; 0 = never
+                             // (HIPENC_SMALL_ROWS; measured crossover with the split-K tiled GEMM: 256 rows 1.72 vs 2.11 ms,
+                             // 512 rows 2.37 vs 2.17 ms)
 
     // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
     static int skinny_split(int K) { return (K + 1023) / 1024; }
