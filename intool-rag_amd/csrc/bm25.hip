@@ -223,23 +223,71 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
         if (best) best = wave_bisect_threshold(v, best, top + 1, K1, 10);
     }
     if (dp && tid == 0) dp[3] = wall_clock64();
-    WaveListPacked L;
-    L.init();
-    u64 tau = best ? ((u64)best << 32) - 1 : 0;
+    // Survivors: positive accumulators at or above the threshold.  When there are at most 128 of them (the bisection
+    // aims at K1 .. 1.5 K1, a bound inherited from other tiles leaves fewer) they are COMPACTED into this wave's own
+    // quarter of the tile (its accumulators are in registers by now; no other wave reads that quarter) and RANKED --
+    // every lane counts the keys above its own one or two, keys are unique (score bits | document), so rank = final
+    // position: ~64 ballots + ~m broadcast reads instead of 64 conditional serial inserts into a sorted wave list.
+    const float thrf = best ? unord32(best) : 0.f;
+    const i64 o = (((i64)q * gridDim.y + tile) * 4 + wv) * K1;
+    if (tlen < (u32)kTileDocs) {   // last, partial tile only: accumulators past the end of the collection never count
+#pragma unroll
+        for (int n = 0; n < NV * 4; ++n) {
+            const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+            if (local >= tlen) v[n] = -INFINITY;
+        }
+    }
+    // one pass: a survivor (v >= threshold; non-positive accumulators are -inf by now) is rare -- ~75 of a wave's 4096 --
+    // so most of the 64 steps are one compare and one scalar branch
+    u64* comp = reinterpret_cast<u64*>(tacc + wv * (kTileDocs / 4));
+    int ms = 0;
 #pragma unroll
     for (int n = 0; n < NV * 4; ++n) {
-        const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
-        u64 c = 0;
-        if (v[n] > 0.f && local < tlen) c = pack_key(v[n], tlo + local);
-        tau = L.offer(c, K1, tau);
+        const bool keep = v[n] >= thrf;
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+            if (keep) {
+                const int pos = ms + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+                if (pos < 128) comp[pos] = pack_key(v[n], tlo + local);
+            }
+            ms += __popcll(mask);
+        }
     }
-    if (lane < K1) {
-        const i64 o = (((i64)q * gridDim.y + tile) * 4 + wv) * K1 + lane;
-        ck[o] = L.e & 0xFFFFFFFF00000000ull;
-        ci[o] = L.e ? (i64)packed_index(L.e) : -1;
+    if (ms <= 128) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done before it reads them back
+        const u64 k0 = lane < ms ? comp[lane] : 0ull, k1 = 64 + lane < ms ? comp[64 + lane] : 0ull;
+        int r0 = 0, r1 = 0;
+#pragma unroll 4
+        for (int j = 0; j < ms; ++j) {
+            const u64 kj = comp[j];   // same address in every lane: an LDS broadcast
+            r0 += kj > k0;
+            r1 += kj > k1;
+        }
+        if (lane < K1 && lane >= ms) { ck[o + lane] = 0; ci[o + lane] = -1; }
+        if (k0 != 0 && r0 < K1) { ck[o + r0] = k0 & 0xFFFFFFFF00000000ull; ci[o + r0] = (i64)packed_index(k0); }
+        if (k1 != 0 && r1 < K1) { ck[o + r1] = k1 & 0xFFFFFFFF00000000ull; ci[o + r1] = (i64)packed_index(k1); }
+        // this wave holds K1 documents at or above the key of rank K1 - 1: publish the bound
+        if (k0 != 0 && r0 == K1 - 1) atomicMax(theta + q, (u32)(k0 >> 32));
+        if (k1 != 0 && r1 == K1 - 1) atomicMax(theta + q, (u32)(k1 >> 32));
+    } else {
+        WaveListPacked L;
+        L.init();
+        u64 tau = best ? ((u64)best << 32) - 1 : 0;
+#pragma unroll
+        for (int n = 0; n < NV * 4; ++n) {
+            const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+            u64 c = 0;
+            if (v[n] > 0.f && local < tlen) c = pack_key(v[n], tlo + local);
+            tau = L.offer(c, K1, tau);
+        }
+        if (lane < K1) {
+            ck[o + lane] = L.e & 0xFFFFFFFF00000000ull;
+            ci[o + lane] = L.e ? (i64)packed_index(L.e) : -1;
+        }
+        const u64 kth = L.kth(K1);   // this wave holds K1 documents at or above it: publish the bound
+        if (lane == 0 && kth != 0) atomicMax(theta + q, (u32)(kth >> 32));
     }
-    const u64 kth = L.kth(K1);   // this wave holds K1 documents at or above it: publish the bound
-    if (lane == 0 && kth != 0) atomicMax(theta + q, (u32)(kth >> 32));
     if (dp && tid == 0) dp[4] = wall_clock64();
 }
 
