@@ -53,6 +53,27 @@ def test_bm25_ties_and_zero_scores(gpu):
     assert np.all(i[2] == -1)
 
 
+def test_bm25_mass_ties_across_tiles(gpu):
+    """A few distinct texts repeated over two document tiles: thousands of exact score ties per wave (more survivors than
+    the compaction buffer holds -> the sorted-list path) next to queries with a handful of survivors (the compaction +
+    rank path); ids and scores equal to the oracle's at k below, at and above the per-wave list sizes."""
+    from hiprag import HipBM25, build_postings_from_texts
+    rng = np.random.default_rng(31)
+    words = [f"w{j}" for j in range(12)]
+    base = [" ".join(rng.choice(words, size=int(rng.integers(1, 5)))) for _ in range(9)]
+    texts = [base[int(t)] for t in rng.integers(0, len(base), size=20000)]
+    texts[777] = "w0 w1 w2 rareterm"
+    texts[19000] = "rareterm rareterm w3"
+    p = build_postings_from_texts(texts)
+    op = ho.build_postings_from_texts(texts)
+    ix = HipBM25(p)
+    q = [ix.terms_of(" ".join(rng.choice(words, size=3))) for _ in range(5)] + [ix.terms_of("rareterm"), ix.terms_of("rareterm w3")]
+    for k in (5, 50, 64):
+        s, i = ix.search(q, k)
+        es, ei = ho.bm25_search(op, q, k)
+        assert np.array_equal(i, ei) and np.array_equal(s, es), k
+
+
 def test_bm25_doc_range_shards_merge_to_unsharded(gpu):
     import torch
     from hiprag import HipBM25, merge_topk_device
