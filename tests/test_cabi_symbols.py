@@ -43,3 +43,19 @@ def test_errors_surface_as_exceptions_without_a_gpu_or_with_bad_args():
     assert "d must be positive" in str(e.value)
     with pytest.raises(nat.HipRagError):
         nat.call("hipidx_destroy", 123456789)
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under intool-rag_amd/ (the shipped host code) may import or execute it,
+    and the C/HIP sources must not include anything from it."""
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parents[1] / "intool-rag_amd"
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|^\s*#\s*include.*oracle|import_module\([\"']oracle|dlopen.*oracle", re.M)
+    offenders = []
+    for f in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.cpp")) + list(root.rglob("*.h")):
+        if "__pycache__" in f.parts or "build" in f.parts:
+            continue
+        if pat.search(f.read_text(errors="ignore")):
+            offenders.append(str(f.relative_to(root)))
+    assert offenders == []
