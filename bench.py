@@ -236,6 +236,24 @@ def main():
                                          f"fp32 C restatement of IndexFlat search (FAISS itself is not installed)",
                                "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
                                "ids_equal_gpu": agree}
+        # SURVEY 8d row (ii), reported beside the faithful port: best-effort CPU -- one batched X @ Q^T on numpy's BLAS
+        # (all host cores) + argpartition; fp32 BLAS summation order, so a near-tie may rank differently from the fp64 truth
+        nb = 64
+        qb = queries[:nb].cpu().numpy()
+        (xh[:50000] @ qb.T).shape                                           # warm BLAS threads
+        t2 = time.perf_counter()
+        sc = xh @ qb.T                                                       # [N, nb]
+        part = np.argpartition(-sc, TOPK, axis=0)[:TOPK]                     # [TOPK, nb], unordered
+        top = np.take_along_axis(sc, part, axis=0)
+        order = np.lexsort((part, -top), axis=0)
+        be_ids = np.take_along_axis(part, order, axis=0).T                   # [nb, TOPK]
+        be_s = time.perf_counter() - t2
+        gbi = index.search_device(queries[:nb], TOPK)[2].cpu().numpy()
+        out["cpu_baseline"]["best_effort"] = {"value": round(nb / be_s, 2), "unit": "queries/s",
+                                              "cores": len(os.sched_getaffinity(0)),
+                                              "sample": f"{nb} queries in one batch: numpy BLAS X @ Q^T on every host core + "
+                                                        f"argpartition top-{TOPK}",
+                                              "ids_equal_gpu_fraction": round(float(np.mean(be_ids == gbi)), 4)}
     # HBM traffic of the scan kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside this
     # process); the committed summary applies to the full-size single-GPU workload only.
     pmc = os.path.join(REPO, "profiles", "r01_pmc_scan.json")
