@@ -1236,9 +1236,11 @@ __global__ __launch_bounds__(64) void fin_final_kernel(FinishArgs a)
 // the queries at k = 50 on the 64-query tiles, where K' is capped at 63 by the wave lists) is NOT sent to the exhaustive
 // path straight away.  fin_final left tau = (k-th exact score so far) - eps; every row that can still enter the top k
 // has a scan value >= tau, so it suffices to re-score the groups whose `first` reaches tau:
-//   roundb_collect_kernel   flagged queries only: compact those group slots (atomic append, cap kRoundBGroups)
-//   roundb_rescore_kernel   all 16 rows of every collected group in fp64
-//   roundb_final_kernel     exact top-k of the <= 4096 rows under (score, id); clears the flag
+//   roundb_collect_kernel   flagged queries only: compact those group slots (atomic append, cap kRoundBGroups), leaving out
+//                           the K' groups the first round already re-scored
+//   roundb_rescore_kernel   the tagged quad of every collected group in fp64
+//   roundb_final_kernel     exact top-k under (score, id) of those rows and the first round's top-k (other quads where a
+//                           `second` demands it); clears the flag
 // Costs one more read of the query's N/16 group values and ~1 MB of rows -- microseconds, against a full fp64 pass over
 // the index for the exhaustive path, which now only sees queries with more than kRoundBGroups such groups (ties).
 // ------------------------------------------------------------------------------------------------------
@@ -1267,6 +1269,8 @@ struct RoundBArgs {
     unsigned long long* roundb_counter;     // queries settled by round B
     int64_t ntotal, id_base, bpw, nblocks;
     int d, P, k, chunk;
+    const u64* sel;            // [nq][64] the first round's selected groups (packed first | slot), sorted; lanes >= K' + 1 zero
+    int Kp;                    // groups the first round re-scored: round B skips them and starts from its top-k
 };
 
 // grid (ceil(ngroups / 4096), nq), 256 threads, 16 values per thread
@@ -1275,6 +1279,9 @@ __global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
     const int q = blockIdx.y;
     if (!a.flags[q]) return;
     const float tau = a.tau[q];
+    // groups the first round already re-scored are exactly those whose packed (first | slot) key is >= the K'-th selected
+    // one (keys are unique); their rows are represented by the first round's top-k, which roundb_final starts from
+    const u64 e_last = a.sel[(int64_t)q * 64 + a.Kp - 1];
     const float* src = a.gmax + (int64_t)q * a.gstride;
     const int64_t base = (int64_t)blockIdx.x * 4096 + threadIdx.x * 4;
     // all four loads first (unconditional; the row of gmax is padded to gstride >= ngroups rounded up to 4 -- past
@@ -1294,7 +1301,7 @@ __global__ __launch_bounds__(256) void roundb_collect_kernel(RoundBArgs a)
             if (i + t >= a.ngroups) v[t] = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (v[t] >= tau && v[t] > -1.0e38f) {
+            if (v[t] >= tau && v[t] > -1.0e38f && e_last != 0 && pack_key(v[t], (u32)(i + t)) < e_last) {
                 const int pos = atomicAdd(a.count + q, 1);
                 if (pos < kRoundBGroups) a.slots[(int64_t)q * kRoundBGroups + pos] = (u32)(i + t);
             }
@@ -1353,6 +1360,19 @@ __global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
     const u64 t0 = wave_kth_of_lanes(m, a.k);
     WaveListPair F;
     F.init();
+    {   // start from the first round's exact top-k (fin_final wrote it): every row it re-scored is either in there or beaten
+        u64 sk = 0;
+        i64 si = -1;
+        if (lane < a.k) {
+            const i64 id = a.out_ids[(int64_t)q * a.k + lane];
+            if (id >= 0) {
+                const double s = a.out64[(int64_t)q * a.k + lane];
+                sk = ord64(METRIC == HIPRAG_METRIC_IP ? s : -s);
+                si = id - a.id_base;
+            }
+        }
+        F.offer(sk, si, a.k);
+    }
     for (int i0 = 0; i0 < ncand; i0 += 64) {
         const int i = i0 + lane;
         const u64 kk = i < ncand ? ck[i] : 0ull;
@@ -1835,7 +1855,7 @@ struct DenseIndex {
             rb.flags = flags; rb.tau = rb_tau; rb.count = rb_count; rb.slots = rb_slots; rb.bk = rb_k; rb.bi = rb_i;
             rb.out64 = o64p; rb.out32 = o32p; rb.out_ids = oidp; rb.fallback_counter = fallback_counter();
             rb.roundb_counter = roundb_counter(); rb.ntotal = ntotal; rb.id_base = id_base; rb.bpw = fa.bpw; rb.nblocks = nb;
-            rb.d = d; rb.P = P; rb.k = k; rb.chunk = w.chunk;
+            rb.d = d; rb.P = P; rb.k = k; rb.chunk = w.chunk; rb.sel = fa.sel; rb.Kp = Kp;
             rb.bsec = rb_sec; rb.gmax2 = fa.gmax2; rb.qn2 = fa.qn2; rb.max_norm2_bits = fa.max_norm2_bits; rb.split = fa.split;
             hipLaunchKernelGGL(roundb_collect_kernel, dim3((unsigned)std::max<int64_t>(1, (ngroups + 4095) / 4096), nq), dim3(256), 0, st, rb);
             hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(8, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
