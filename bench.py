@@ -200,7 +200,8 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16 x bf16 -> f32 filter scan, f64 re-score of the f32 rows",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10",
+        "config": {"workload": ("configs[1]: 1M x 1024-d synthetic unit vectors, brute-force inner-product top-10" if n_rows == N_ROWS
+                                else f"--rows override: {n_rows} x 1024-d synthetic unit vectors, brute-force inner-product top-10"),
                    "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH, "passes_per_step": PASSES,
                    "queries_per_pass": index.pass_queries,
                    "sharding": f"rows/{world}" if world > 1 else "none",
