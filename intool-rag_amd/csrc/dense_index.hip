@@ -1596,6 +1596,8 @@ struct DenseIndex {
         if (ms) scan_mode = ms[0] == 'f' ? 0 : ms[0] == 's' ? 1 : ms[0] == 'q' ? 2 : 3;
         const char* lq = getenv("HIPRAG_LAUNCH_QUERIES");
         launch_env = lq ? atoi(lq) : 0;
+        if (const char* sw = getenv("HIPRAG_SCAN_WAVES_SMALL")) scan_waves_small = atoi(sw);
+        if (const char* sb = getenv("HIPRAG_SCAN_WAVES_SMALL_BLOCKS")) scan_waves_small_blocks = std::max(1, atoi(sb));
         update_launch_q();
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
@@ -1680,6 +1682,12 @@ struct DenseIndex {
     // unit vectors: k + 12 certifies every query at k = 10 but only 99 % at k = 20; the 64-entry wave lists cap K' at 63,
     // where about half of the k = 50 queries -- the reference's retrieval depth, page_retriever.py:92 -- fail the
     // certificate and are settled by round B of the finish instead).  k > 57 uses the 32-query split scan.
+    // Small shards (an 8-GPU row split of 1M rows leaves 125 k per GPU): with 8 waves per workgroup a wave streams two or
+    // three 32-row blocks per pass; 4-wave workgroups stream twice as many each and leave half of every SIMD's registers to
+    // the tail kernels of earlier steps.  Measured (1024 queries per launch, pipelined): 125 k rows 945 -> 902 us per step,
+    // 250 k 1640 -> 1590, 500 k 2758 -> 2857 (slower), 1M equal -- so below 5 blocks per wave of the 8-wave partition.
+    int scan_waves_small = 1;          // HIPRAG_SCAN_WAVES_SMALL=0 keeps 8 waves everywhere
+    int scan_waves_small_blocks = 5;   // HIPRAG_SCAN_WAVES_SMALL_BLOCKS
     int mode_for(int k) const { return (scan_mode >= 2 && k > kMaxK64) ? 1 : scan_mode; }
     int pass_queries_for(int k) const { return mode_for(k) >= 2 ? 64 : 32; }
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
@@ -1760,9 +1768,13 @@ struct DenseIndex {
             const int P2 = P / 2;
             const bool one_pass = nq <= 64;
             void (*scan)(ScanArgs);
-            const int nw = 8;   // a third wave per SIMD (12 per workgroup) does not fit 168 registers: 83 spills
+            int nw = 8;   // a third wave per SIMD (12 per workgroup) does not fit 168 registers: 83 spills
             if (P2 % 16 == 0) scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false> : scan_bf16_kernel<METRIC, 8, 16, true>;
             else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 8, false> : scan_bf16_kernel<METRIC, 8, 8, true>;
+            if (scan_waves_small > 0 && P2 % 16 == 0 && nb < (int64_t)scan_cus * 8 * scan_waves_small_blocks) {
+                nw = 4;   // small shard (see scan_waves_small)
+                scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false> : scan_bf16_kernel<METRIC, 4, 16, true>;
+            }
             w.waves = nw;
             w.chunk = 8;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
