@@ -252,6 +252,41 @@ def test_hip_embedding_provider_and_reranker_follow_reference_behaviour(gpu, mon
     assert all("rerank_score" in c.metadata for c in out)
 
 
+def test_provider_loads_weights_and_tokenizer_from_local_files(gpu, tmp_path, monkeypatch):
+    """HIP_ENCODER_WEIGHTS (safetensors, XLM-R parameter names -- here with the `roberta.` prefix checkpoints
+    of sequence-classification heads carry) + HIP_TOKENIZER_FILE + HIP_ENCODER_CONFIG build the provider the factory
+    returns; its embedding equals the encoder run directly on the same state and token ids."""
+    import rag.llm.embeddings.factory as fac
+    from safetensors.torch import save_file
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    cfg = EncoderConfig(vocab=64, hidden=128, layers=2, heads=2, ffn=256, max_pos=40, max_seq_len=32)
+    sd = random_state(cfg, seed=3)
+    save_file({("roberta." + k): v.contiguous() for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    tk = Tokenizer(WordLevel({"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3, "hello": 4, "world": 5, "bank": 6, "payment": 7,
+                              "ref": 8}, unk_token="<unk>"))
+    tk.pre_tokenizer = Whitespace()
+    tk.save(str(tmp_path / "tokenizer.json"))
+    monkeypatch.setenv("HIP_ENCODER_WEIGHTS", str(tmp_path / "model.safetensors"))
+    monkeypatch.setenv("HIP_TOKENIZER_FILE", str(tmp_path / "tokenizer.json"))
+    monkeypatch.setenv("HIP_ENCODER_CONFIG", json.dumps({"vocab": 64, "hidden": 128, "layers": 2, "heads": 2, "ffn": 256,
+                                                         "max_pos": 40, "max_seq_len": 32}))
+    monkeypatch.setenv("EMBEDDING_PROVIDER", "hip")
+    fac.set_embedding_provider(None)
+    try:
+        prov = fac.get_embedding_provider()
+        assert prov.dimension() == 128 and not prov.tokenizer.synthetic
+        got = np.asarray(asyncio.run(prov.embed_single("hello world")), dtype=np.float32)
+        ref = HipEncoder(cfg, sd).encode_tokens([[0, 4, 5, 2]]).cpu().numpy()[0]
+        assert np.array_equal(got, ref)
+        batch = np.asarray(asyncio.run(prov.embed_batch(["hello world", "", "bank payment ref"])), dtype=np.float32)
+        assert np.array_equal(batch[0], ref) and batch.shape == (3, 128)
+    finally:
+        fac.set_embedding_provider(None)
+
+
 def test_overlay_reads_index_files_written_by_the_reference_format(gpu, tmp_path, monkeypatch):
     """A STORAGE_DIR that only holds `{doc}_faiss.index` (the reference's own file) is searchable as is."""
     import rag.storage.hip_index as hi

@@ -95,3 +95,32 @@ def test_service_facade_uses_the_installed_provider():
         assert service.embedding_dim() == 1
     finally:
         f.set_embedding_provider(None)
+
+
+def _tiny_tokenizer_file(path):
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3, "hello": 4, "world": 5, "bank": 6, "payment": 7, "ref": 8}
+    tk = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = Whitespace()
+    tk.save(str(path))
+    return vocab
+
+
+def test_file_tokenizer_hook_wraps_ids_like_xlmr(tmp_path, monkeypatch):
+    """a local tokenizer.json (HIP_TOKENIZER_FILE) replaces the synthetic hashing tokenizer; sequences are
+    framed like XLM-R's: <s> ids </s> for one text, <s> a </s></s> b </s> for a pair, truncated to max_len."""
+    from rag.providers.hip.tokenizer import FileTokenizer, HashTokenizer, load_tokenizer
+    f = tmp_path / "tokenizer.json"
+    _tiny_tokenizer_file(f)
+    monkeypatch.setenv("HIP_TOKENIZER_FILE", str(f))
+    tk = load_tokenizer(vocab=100)
+    assert isinstance(tk, FileTokenizer) and not tk.synthetic
+    assert tk.encode("hello world", 16) == [0, 4, 5, 2]
+    assert tk.encode("hello zzz world", 16) == [0, 4, 3, 5, 2]                  # unknown word -> <unk>
+    assert tk.encode("hello world hello world", 4) == [0, 4, 5, 2]              # truncated to max_len incl. <s> </s>
+    assert tk.encode_pair("bank ref", "payment world hello", 16) == [0, 6, 8, 2, 2, 7, 5, 4, 2]
+    assert tk.encode_pair("bank ref", "payment world hello", 7) == [0, 6, 8, 2, 2, 7, 2]
+    monkeypatch.delenv("HIP_TOKENIZER_FILE")
+    assert isinstance(load_tokenizer(vocab=100), HashTokenizer)
