@@ -25,6 +25,10 @@ class Config:
     HIP_INDEX_METRIC = os.getenv("HIP_INDEX_METRIC", "l2")       # the reference builds IndexFlatL2 (faiss_index.py:123)
     HIP_DEVICE = int(os.getenv("HIP_DEVICE", "0"))
     HIP_COMPAT_MINUS_ONE = os.getenv("HIP_COMPAT_MINUS_ONE", "true").lower() == "true"
+    # false (default): `instruction` arguments are accepted and ignored, exactly like the reference's HF provider
+    # (hf/embeddings.py:45,64-65); true: a given instruction is prepended to each text before tokenisation (BGE recipe)
+    HIP_APPLY_INSTRUCTION = os.getenv("HIP_APPLY_INSTRUCTION", "false").lower() == "true"
+    EMBEDDING_PASSAGE_INSTRUCTION = os.getenv("EMBEDDING_PASSAGE_INSTRUCTION", "")
     # false (default): search the FIRST index file only, like the reference (faiss_index.py:162-167); true: every document
     HIP_SEARCH_ALL_DOCUMENTS = os.getenv("HIP_SEARCH_ALL_DOCUMENTS", "false").lower() == "true"
 

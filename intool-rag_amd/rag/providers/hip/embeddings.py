@@ -5,7 +5,8 @@ rag/providers/hip/embeddings.py -- MI355X embedding provider behind the referenc
 Behaviour mirrors HuggingFaceEmbeddingProvider (rag/providers/hf/embeddings.py:13-91) call for call:
   * embed_single: strip; empty / blank -> [0.0] * dim (:47-48); else encode in a worker thread (asyncio.to_thread, :53)
   * embed_batch : [] -> []; per-text strip, None / blank -> "" which IS encoded (:70-73); one batched encode (:76);
-                  `instruction` and `batch_size` accepted and ignored exactly like the reference (:45, :64-65)
+                  `instruction` and `batch_size` accepted and ignored exactly like the reference (:45, :64-65);
+                  HIP_APPLY_INSTRUCTION=true prepends a given instruction instead (rag/config.py:53-60 defines them)
   * LangChain's HuggingFaceEmbeddings replaces "\\n" by " " before encoding and asks sentence-transformers for
     normalize_embeddings=True (:34): CLS pooling + L2 normalisation happen on the GPU (csrc/encoder.hip pool_kernel)
   * dimension(): the model width (the reference probes it with a dummy encode, :37-38)
@@ -84,6 +85,8 @@ class HipEmbeddingProvider(EmbeddingProvider):
         if not text or not text.strip():
             return [0.0] * self._dimension
         clean_text = text.strip()
+        if instruction and config.HIP_APPLY_INSTRUCTION:
+            clean_text = instruction + clean_text
         try:
             vectors = await asyncio.to_thread(self._encode, [clean_text])
             return vectors[0]
@@ -95,6 +98,8 @@ class HipEmbeddingProvider(EmbeddingProvider):
         if not texts:
             return []
         clean_texts = [t.strip() if t and t.strip() else "" for t in texts]
+        if instruction and config.HIP_APPLY_INSTRUCTION:
+            clean_texts = [instruction + t if t else t for t in clean_texts]
         try:
             vectors = await asyncio.to_thread(self._encode, clean_texts)
             return [v if v else [0.0] * self._dimension for v in vectors]

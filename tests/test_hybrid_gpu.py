@@ -283,6 +283,14 @@ def test_provider_loads_weights_and_tokenizer_from_local_files(gpu, tmp_path, mo
         assert np.array_equal(got, ref)
         batch = np.asarray(asyncio.run(prov.embed_batch(["hello world", "", "bank payment ref"])), dtype=np.float32)
         assert np.array_equal(batch[0], ref) and batch.shape == (3, 128)
+        # instruction prefixes: ignored like the reference by default, prepended with HIP_APPLY_INSTRUCTION
+        import rag.providers.hip.embeddings as pe
+        with_instr = np.asarray(asyncio.run(prov.embed_single("world", instruction="hello ")), dtype=np.float32)
+        assert np.array_equal(with_instr, np.asarray(asyncio.run(prov.embed_single("world")), dtype=np.float32))
+        monkeypatch.setattr(pe.config, "HIP_APPLY_INSTRUCTION", True, raising=False)
+        assert np.array_equal(np.asarray(asyncio.run(prov.embed_single("world", instruction="hello ")), dtype=np.float32), ref)
+        b2 = np.asarray(asyncio.run(prov.embed_batch(["world", ""], instruction="hello ")), dtype=np.float32)
+        assert np.array_equal(b2[0], ref)
     finally:
         fac.set_embedding_provider(None)
 
