@@ -42,6 +42,12 @@ int32_t hiprag_version(void);
 const char* hiprag_last_error(void);
 int32_t hiprag_device_count(int32_t* out_count);
 int32_t hiprag_device_sync(int32_t device);
+/* Optional process-level bracket: init checks that n_devices GPUs are visible (<= 0: at least one) and
+ * creates their contexts up front; shutdown synchronises every device and drops every handle still registered (their
+ * device memory goes with them) -- the reference has no counterpart, its indices live until the process exits
+ * (`_INDEX_CACHE`, rag/storage/faiss_index.py:24). */
+int32_t hiprag_init(int32_t n_devices);
+int32_t hiprag_shutdown(void);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the stream they run on). */
 int32_t hiprag_event_create(uint64_t* out_event);
@@ -165,6 +171,15 @@ int32_t hiprrf_fuse(const int64_t* ids_a_host, const int64_t* ids_b_host, int32_
 int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int32_t nq, int32_t depth_a,
                         int32_t depth_b, int32_t k, float c, float w_a, float w_b, float* out_scores_dev,
                         int64_t* out_ids_dev, void* stream);
+
+/* ---- hybrid fast path: one call = dense top-`depth` + BM25 top-`depth` + RRF -> top-k -------------------
+ * What rag/query/retriever.py does per query batch with three calls, for hosts that bind the C-ABI directly: host
+ * queries and term lists in, fused fp32 scores / ids out; the two result lists never leave the GPU.  Both handles must
+ * live on the same device.  Row-sharded serving keeps using the three calls (the all-gather sits between search and
+ * fusion, hiprag/sharded.py) -- ranks are global, so fusion has to follow the merge. */
+int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
+                         const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
+                         float w_sparse, float* out_scores, int64_t* out_ids);
 
 /* ---- batch encoder: XLM-RoBERTa-large architecture (BGE-M3 embeddings, bge-reranker-v2-m3 cross-encoder) ---------
  * forward     <- HuggingFaceEmbeddings.embed_query / embed_documents (sentence-transformers encode, CLS pooling,

@@ -515,6 +515,8 @@ Registry<Bm25Index>& reg()
     HR_CHECK_HIP(hipSetDevice(ix->device))
 
 }  // namespace
+
+size_t clear_bm25_registry() { return reg().clear(); }
 }  // namespace hiprag
 
 using namespace hiprag;

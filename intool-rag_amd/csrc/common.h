@@ -56,6 +56,13 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         return map_.erase(h) != 0;
     }
+    size_t clear()   // drops every handle (hiprag_shutdown); objects die when their last user lets go
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        const size_t n = map_.size();
+        map_.clear();
+        return n;
+    }
 
 private:
     std::mutex mu_;
@@ -88,5 +95,10 @@ struct DevBuf {
     template <typename T>
     T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// hiprag_shutdown: every translation unit owns the registry of its handle type
+size_t clear_dense_registry();
+size_t clear_bm25_registry();
+size_t clear_encoder_registry();
 
 }  // namespace hiprag

@@ -1960,6 +1960,8 @@ Registry<DenseIndex>& reg()
     HR_CHECK_HIP(hipSetDevice(ix->device))
 
 }  // namespace
+
+size_t clear_dense_registry() { return reg().clear(); }
 }  // namespace hiprag
 
 using namespace hiprag;

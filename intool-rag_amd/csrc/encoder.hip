@@ -852,6 +852,8 @@ Registry<Encoder>& reg()
 }
 
 }  // namespace
+
+size_t clear_encoder_registry() { return reg().clear(); }
 }  // namespace hiprag
 
 using namespace hiprag;

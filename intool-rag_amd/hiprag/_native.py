@@ -40,6 +40,10 @@ f32p, f64p, i64p, i32p, u32p, u64p = (POINTER(c_float), POINTER(c_double), POINT
 SIGNATURES = {
     "hiprag_device_count": [i32p],
     "hiprag_device_sync": [c_int32],
+    "hiprag_init": [c_int32],
+    "hiprag_shutdown": [],
+    "hiphybrid_search": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float,
+                         c_float, c_void_p, c_void_p],
     "hiprag_event_create": [u64p],
     "hiprag_event_record": [c_uint64, c_void_p],
     "hiprag_event_elapsed_ms": [c_uint64, c_uint64, f32p],

@@ -38,3 +38,21 @@ def rrf_fuse_device(ids_a, ids_b, k: int, c: float = RRF_C, w_a: float = 1.0, w_
     nat.call("hiprrf_fuse_dev", ids_a.data_ptr(), ids_b.data_ptr(), nq, ids_a.shape[1], ids_b.shape[1], int(k), float(c),
              float(w_a), float(w_b), out[0].data_ptr(), out[1].data_ptr(), _stream_ptr())
     return out
+
+
+def hybrid_search(index, bm25, queries, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0,
+                  w_dense: float = 1.0, w_sparse: float = 1.0) -> Tuple[np.ndarray, np.ndarray]:
+    """hiphybrid_search: dense top-`depth` + BM25 top-`depth` + RRF -> top-k in ONE library call (host arrays in and out,
+    the two intermediate lists stay on the GPU).  `index` is a HipFlatIndex, `bm25` a HipBM25 on the same device,
+    `queries` [nq, d] float32, `sparse_queries` nq lists of term ids.  Returns (scores float32 [nq, k], ids int64 [nq, k])."""
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+    if q.ndim != 2 or q.shape[1] != index.d or len(sparse_queries) != q.shape[0]:
+        raise ValueError("queries must be [nq, d] with one term list per query")
+    terms, qoff = bm25._flatten(sparse_queries)
+    nq = q.shape[0]
+    scores = np.empty((nq, k), dtype=np.float32)
+    ids = np.empty((nq, k), dtype=np.int64)
+    nat.call("hiphybrid_search", index._h, bm25._h, q.ctypes.data, terms.ctypes.data if terms.size else None,
+             qoff.ctypes.data, nq, int(depth), int(k), float(c), float(w_dense), float(w_sparse), scores.ctypes.data,
+             ids.ctypes.data)
+    return scores, ids

@@ -13,6 +13,7 @@ from oracle import hybrid_oracle as ho
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
 GOLD = json.load(open(os.path.join(HERE, "golden", "reference_wrapper_golden.json")))
 
 
@@ -113,6 +114,54 @@ def test_rrf_matches_oracle_bit_exact(gpu):
         es, ei = ho.rrf_fuse(a, b, k, c=c, w_a=wa, w_b=wb)
         assert np.array_equal(i, ei)
         assert np.array_equal(s, es)
+
+
+def test_hybrid_fast_path_one_call_and_library_bracket(gpu):
+    """hiphybrid_search (dense top-depth + BM25 top-depth + RRF in one C-ABI call) against the oracle's three steps, and
+    hiprag_init / hiprag_shutdown: shutdown drops every handle, the wrappers then report an unknown handle."""
+    import hiprag
+    from hiprag import HipBM25, HipFlatIndex, HipRagError, hybrid_search
+    hiprag.init(1)
+    with pytest.raises(HipRagError):
+        hiprag.init(4096)                                            # more devices than any node has
+    n, d, depth, k = 6000, 96, 50, 10
+    x = ho.synthetic_vectors(n, d, seed=41)
+    q = ho.synthetic_queries(9, d, seed=42)
+    p = ho.synthetic_postings(n, n_terms=512, seed=43)
+    sq = ho.synthetic_sparse_queries(9, n_terms=512, terms_per_query=5, seed=44, min_rank=4)
+    sq[2] = np.asarray([], dtype=np.uint32)                          # a query without sparse terms: dense list only
+    ix = HipFlatIndex(d, "ip")
+    ix.add(x)
+    bm = HipBM25(_gpu_postings(p))
+    for (c, wd, ws) in [(60.0, 1.0, 1.0), (60.0, 0.7, 0.3)]:
+        s, i = hybrid_search(ix, bm, q, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
+        _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
+        _, bi = ho.bm25_search(p, sq, depth)
+        es, ei = ho.rrf_fuse(di, bi, k, c=c, w_a=wd, w_b=ws)
+        assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # shutdown drops EVERY handle of the process, so it is exercised in a process of its own
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import hiprag\n"
+        "from hiprag import HipFlatIndex, HipRagError\n"
+        "hiprag.init(1)\n"
+        "x = np.random.default_rng(0).standard_normal((300, 64)).astype(np.float32)\n"
+        "ix = HipFlatIndex(64, 'ip'); ix.add(x)\n"
+        "assert ix.search(x[:2], 3)[1][:, 0].tolist() == [0, 1]\n"
+        "hiprag.shutdown()\n"
+        "try:\n"
+        "    ix.search(x[:2], 3); raise SystemExit('handle survived the shutdown')\n"
+        "except HipRagError:\n"
+        "    pass\n"
+        "ix._h = None\n"
+        "ix2 = HipFlatIndex(64, 'ip'); ix2.add(x[:100])\n"
+        "assert ix2.search(x[:1], 3)[1][0, 0] == 0\n"
+        "print('bracket ok')\n") % (REPO, os.path.join(REPO, "intool-rag_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bracket ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_overlay_search_matches_reference_golden(gpu, tmp_path, monkeypatch):
