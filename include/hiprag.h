@@ -68,6 +68,10 @@ int32_t hiprag_event_destroy(uint64_t event);
  * Returned ids are row numbers in insertion order plus the index's id_base (row-sharded indices).
  * Inputs must be finite.
  */
+/* One handle = one GPU's rows (`device`).  SURVEY 8b sketched a `n_shards` argument here; this library shards the way the
+ * hardware is driven instead -- one process per GPU, each with its own handle over a contiguous row range
+ * (`hipidx_set_id_base` makes its ids global), partial top-k merged after ONE all-gather by `hiprag_merge_topk_dev`
+ * (hiprag/sharded.py).  The same holds for `hipbm25_create` (document-range shards, `hipbm25_set_id_base`). */
 int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_handle);
 int32_t hipidx_destroy(uint64_t h);
 int32_t hipidx_add(uint64_t h, const float* x_host, int64_t n);
