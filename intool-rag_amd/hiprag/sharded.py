@@ -206,3 +206,72 @@ class EmulatedShards:
         for g, ix in enumerate(self.shards):
             ix.search_device(q, k, out=(gathered[g, 0].view(torch.float64), s32, gathered[g, 1]))
         return merge_topk_device(gathered[:, 0].view(torch.float64), gathered[:, 1], k, self.shards[0].metric)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Row-sharded HYBRID search (BASELINE configs[3]): dense rows and BM25 postings are partitioned by the SAME
+# document ranges (idf and avgdl are global constants baked into the impacts when the postings are built, so a shard's
+# scores equal the unsharded ones).  A batch is: local dense top-`depth` + local BM25 top-`depth` -> ONE all-gather of
+# both partial lists packed into a single buffer ([leg, {score bits, ids}, nq, depth] int64) -> every rank merges each
+# leg with the canonical comparator (score, id) -> RRF over the two GLOBAL lists (ranks are global: fusing per shard
+# and merging afterwards would be a different function).
+# ---------------------------------------------------------------------------------------------------------
+def _pack_hybrid(dense: HipFlatIndex, bm25, q, sparse_queries, depth: int, pack):
+    import torch
+    nq = q.shape[0]
+    s32 = torch.empty((nq, depth), dtype=torch.float32, device=q.device)
+    dense.search_device(q, depth, out=(pack[0, 0].view(torch.float64), s32, pack[0, 1]))
+    bm25.search_device(sparse_queries, depth, out=(pack[1, 0].view(torch.float64), s32, pack[1, 1]))
+
+
+def _merge_and_fuse(gathered, depth: int, k: int, metric, c: float, w_dense: float, w_sparse: float):
+    """gathered: [parts, 2 legs, 2, nq, depth] int64 -> (fused scores float32 [nq,k], ids int64 [nq,k])."""
+    import torch
+    from ._native import METRIC_IP
+    from .fusion import rrf_fuse_device
+    dl = merge_topk_device(gathered[:, 0, 0].view(torch.float64), gathered[:, 0, 1], depth, metric)
+    sl = merge_topk_device(gathered[:, 1, 0].view(torch.float64), gathered[:, 1, 1], depth, METRIC_IP)   # BM25: higher is better
+    return rrf_fuse_device(dl[2], sl[2], k, c, w_dense, w_sparse)
+
+
+class ShardedHybrid:
+    def __init__(self, dense: HipFlatIndex, bm25, row_lo: int = 0, group=None):
+        import torch.distributed as dist
+        self.dense, self.bm25, self.group = dense, bm25, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dense.set_id_base(row_lo)
+        bm25.set_id_base(row_lo)
+
+    def search_device(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
+                      w_sparse: float = 1.0):
+        """q: float32 CUDA tensor [nq, d] (the same on every rank); sparse_queries: nq term-id lists.  Every rank
+        returns the same fused (scores float32 [nq,k], ids int64 [nq,k])."""
+        import torch
+        nq = q.shape[0]
+        pack = torch.empty((2, 2, nq, depth), dtype=torch.int64, device=q.device)
+        _pack_hybrid(self.dense, self.bm25, q, sparse_queries, depth, pack)
+        if self.world == 1:
+            gathered = pack.unsqueeze(0)
+        else:
+            gathered = torch.empty((self.world,) + tuple(pack.shape), dtype=torch.int64, device=q.device)
+            all_gather_packed(pack, gathered, self.group, async_op=False)
+        return _merge_and_fuse(gathered, depth, k, self.dense.metric, c, w_dense, w_sparse)
+
+
+class EmulatedHybridShards:
+    """ShardedHybrid's partition / merge / fuse with every shard on ONE device and no collective (tests)."""
+
+    def __init__(self, shards, bounds: List[Tuple[int, int]]):
+        self.shards = shards           # [(HipFlatIndex, HipBM25)], document ranges `bounds`
+        for (ix, bm), (lo, _) in zip(shards, bounds):
+            ix.set_id_base(lo)
+            bm.set_id_base(lo)
+
+    def search_device(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
+                      w_sparse: float = 1.0):
+        import torch
+        nq = q.shape[0]
+        gathered = torch.empty((len(self.shards), 2, 2, nq, depth), dtype=torch.int64, device=q.device)
+        for g, (ix, bm) in enumerate(self.shards):
+            _pack_hybrid(ix, bm, q, sparse_queries, depth, gathered[g])
+        return _merge_and_fuse(gathered, depth, k, self.shards[0][0].metric, c, w_dense, w_sparse)

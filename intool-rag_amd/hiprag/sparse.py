@@ -106,6 +106,10 @@ class HipBM25:
         if id_base:
             nat.call("hipbm25_set_id_base", self._h, int(id_base))
 
+    def set_id_base(self, base: int) -> None:
+        """First global document id of this (document-range) shard: returned ids are local id + base."""
+        nat.call("hipbm25_set_id_base", self._h, int(base))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             try:

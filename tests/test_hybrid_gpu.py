@@ -98,6 +98,40 @@ def test_bm25_doc_range_shards_merge_to_unsharded(gpu):
     assert np.array_equal(m32.cpu().numpy(), es)
 
 
+def test_row_sharded_hybrid_equals_unsharded(gpu):
+    """SURVEY 8e / configs[3]: dense rows and postings split by the same document ranges, both partial lists in one
+    packed buffer (what the single all-gather carries), each leg merged globally, RRF after the merge -- identical to the
+    unsharded hybrid result; and ShardedHybrid itself at world size 1."""
+    import torch
+    from hiprag import HipBM25, HipFlatIndex
+    from hiprag.sharded import EmulatedHybridShards, ShardedHybrid
+    n, d, depth, k = 9000, 64, 50, 10
+    x = ho.synthetic_vectors(n, d, seed=51)
+    q = ho.synthetic_queries(7, d, seed=52)
+    p = ho.synthetic_postings(n, n_terms=512, seed=53)
+    sq = ho.synthetic_sparse_queries(7, n_terms=512, terms_per_query=5, seed=54, min_rank=4)
+    full = _gpu_postings(p)
+    _, di = ho.flat_search(x, q, depth, ho.METRIC_L2)
+    _, bi = ho.bm25_search(p, sq, depth)
+    qd = torch.from_numpy(q).cuda()
+    for (c, wd, ws) in [(60.0, 1.0, 1.0), (60.0, 0.7, 0.3)]:
+        es, ei = ho.rrf_fuse(di, bi, k, c=c, w_a=wd, w_b=ws)
+        bounds = [(0, 2500), (2500, 2501), (2501, 6000), (6000, 9000)]
+        shards = []
+        for lo, hi in bounds:
+            ix = HipFlatIndex(d, "l2")
+            ix.add(x[lo:hi])
+            shards.append((ix, HipBM25(full.shard(lo, hi))))
+        fs, fi = EmulatedHybridShards(shards, bounds).search_device(qd, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es)
+        one = HipFlatIndex(d, "l2")
+        one.add(x)
+        ss, si = ShardedHybrid(one, HipBM25(full)).search_device(qd, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(si.cpu().numpy(), ei) and np.array_equal(ss.cpu().numpy(), es)
+
+
 def test_rrf_matches_oracle_bit_exact(gpu):
     from hiprag import rrf_fuse
     rng = np.random.default_rng(11)

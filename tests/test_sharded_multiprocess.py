@@ -52,6 +52,33 @@ def _cpu_worker(rank, world, port, q_out):
             ms, mi = ho.merge_partial_topk(parts_s, parts_i, k, metric)
             fs, fi, f64 = ho.flat_search(x, q, k, metric, return_f64=True)
             assert np.array_equal(mi, fi) and np.array_equal(ms, f64)
+        # hybrid: dense + BM25 partial lists of the same document range in ONE packed all-gather
+        # ([leg, {score bits, ids}, nq, depth]), each leg merged globally, RRF after the merge
+        depth = 20
+        p = ho.synthetic_postings(n, n_terms=256, seed=53)
+        sq = ho.synthetic_sparse_queries(nq, n_terms=256, terms_per_query=4, seed=54, min_rank=2)
+        _, dids, d64 = ho.flat_search(x[lo:hi], q, depth, ho.METRIC_IP, id_base=lo, return_f64=True)
+        from hiprag import PostingsCSR
+        sh = PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts).shard(lo, hi)   # local ids, global idf/avgdl
+        bs, bids = ho.bm25_search(ho.Postings(sh.n_docs, sh.n_terms, sh.offsets, sh.doc_ids, sh.impacts), sq, depth)
+        bids = np.where(bids >= 0, bids + lo, bids)
+        pack = torch.empty((2, 2, nq, depth), dtype=torch.int64)
+        pack[0, 0] = torch.from_numpy(d64.view(np.int64))
+        pack[0, 1] = torch.from_numpy(dids)
+        pack[1, 0] = torch.from_numpy(bs.astype(np.float64).view(np.int64))
+        pack[1, 1] = torch.from_numpy(bids)
+        gathered = torch.empty((world,) + tuple(pack.shape), dtype=torch.int64)
+        all_gather_packed(pack, gathered, None, async_op=True).wait()
+        g = gathered.numpy()
+        _, gd = ho.merge_partial_topk([g[r, 0, 0].view(np.float64) for r in range(world)], [g[r, 0, 1] for r in range(world)],
+                                      depth, ho.METRIC_IP)
+        _, gb = ho.merge_partial_topk([g[r, 1, 0].view(np.float64) for r in range(world)], [g[r, 1, 1] for r in range(world)],
+                                      depth, ho.METRIC_IP)
+        fs_, fi_ = ho.rrf_fuse(gd, gb, k)
+        _, di_full = ho.flat_search(x, q, depth, ho.METRIC_IP)
+        _, bi_full = ho.bm25_search(p, sq, depth)
+        es_, ei_ = ho.rrf_fuse(di_full, bi_full, k)
+        assert np.array_equal(fi_, ei_) and np.array_equal(fs_, es_)
         owned = [chunks_of_rank(32, world, r) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(32)) and all(o == list(range(o[0], o[-1] + 1)) for o in owned)
         q_out.put((rank, "ok"))
