@@ -59,3 +59,31 @@ def test_product_package_never_imports_the_oracle():
         if pat.search(f.read_text(errors="ignore")):
             offenders.append(str(f.relative_to(root)))
     assert offenders == []
+
+
+def test_missing_library_raises_instead_of_falling_back(tmp_path):
+    """Without libhiprag.so the product path raises at the first call (and the overlay reports it as the RuntimeError the
+    reference raises for a missing FAISS, faiss_index.py:36-37): there is no CPU code path to fall back to.  Run in a
+    fresh interpreter so that this process's already loaded library is not involved."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "os.environ['HIPRAG_LIB'] = %r\n"
+        "from hiprag import HipFlatIndex, HipRagError, rrf_fuse\n"
+        "for f in (lambda: HipFlatIndex(8, 'ip'), lambda: rrf_fuse(np.zeros((1, 2), np.int64), np.zeros((1, 2), np.int64), 1)):\n"
+        "    try:\n"
+        "        f(); raise SystemExit('no error without the library')\n"
+        "    except HipRagError as e:\n"
+        "        assert 'not found' in str(e)\n"
+        "import rag.storage.hip_index as hi\n"
+        "assert not hi.HAS_HIP\n"
+        "try:\n"
+        "    hi.create_hip_index([[0.0] * 8]); raise SystemExit('overlay did not raise')\n"
+        "except RuntimeError as e:\n"
+        "    assert 'libhiprag' in str(e)\n"
+        "print('raises ok')\n") % (repo, os.path.join(repo, "intool-rag_amd"), str(tmp_path / "absent" / "libhiprag.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "raises ok" in r.stdout, r.stdout + r.stderr
