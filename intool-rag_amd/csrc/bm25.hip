@@ -85,6 +85,9 @@ struct TileSlot {   // posting range of one (query, term slot); skip = first ent
     long long skip;
 };
 
+// IDX32: fewer than 2^30 postings in all, so posting indices and their byte offsets fit 32 bits -- the stream's index
+// arithmetic (a third of its instructions as 64-bit adds, compares and selects) becomes single 32-bit operations.
+template <bool IDX32>
 __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ doc_ids, const float* __restrict__ impacts,
                                                         const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
                                                         const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
@@ -128,10 +131,17 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     auto fetch = [&](u64 i0, u64 b, u32 (&d)[U], float (&im)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {   // eight independent 1 KiB-per-instruction loads of each stream
-            const u64 i = i0 + (u64)j * 256 + tid;
-            const u64 ic = i < b ? i : 0;
-            d[j] = doc_ids[ic];
-            im[j] = impacts[ic];
+            if (IDX32) {
+                const u32 i = (u32)i0 + (u32)j * 256u + (u32)tid;
+                const u32 ic = i < (u32)b ? i : 0u;
+                d[j] = doc_ids[ic];
+                im[j] = impacts[ic];
+            } else {
+                const u64 i = i0 + (u64)j * 256 + tid;
+                const u64 ic = i < b ? i : 0;
+                d[j] = doc_ids[ic];
+                im[j] = impacts[ic];
+            }
         }
     };
     int cs = 0;              // cursor: next chunk to fetch = [cpos, ..) of slot cs
@@ -168,7 +178,9 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const u32 x = dR[r][j] - tlo;
-                dd[j] = (pR[r] + (u64)j * 256 + tid < bR[r] && x < tlen) ? x : 0xFFFFFFFFu;
+                const bool inr = IDX32 ? ((u32)pR[r] + (u32)j * 256u + (u32)tid < (u32)bR[r])
+                                       : (pR[r] + (u64)j * 256 + tid < bR[r]);
+                dd[j] = (inr && x < tlen) ? x : 0xFFFFFFFFu;
                 cur[j] = tacc[dd[j] != 0xFFFFFFFFu ? dd[j] : 0u];
             }
 #pragma unroll
@@ -391,11 +403,14 @@ struct Bm25Index {
         HR_CHECK_HIP(hipMemsetAsync(theta_dev.p, 0, (size_t)nq * sizeof(u32), st));
         static bool lds_ok = false;
         if (!lds_ok) {
-            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kTileDocs * (int)sizeof(float)));
+            HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              kTileDocs * (int)sizeof(float)));
             lds_ok = true;
         }
-        hipLaunchKernelGGL(taat_tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(256), kTileDocs * sizeof(float), st,
+        auto tile_kernel = n_postings < ((i64)1 << 30) ? taat_tile_kernel<true> : taat_tile_kernel<false>;
+        hipLaunchKernelGGL(tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(256), kTileDocs * sizeof(float), st,
                            doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
                            max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), dbg_p);
         if (dbg_p) {
