@@ -75,6 +75,10 @@ int32_t hiprag_event_destroy(uint64_t event);
 int32_t hipidx_create(int32_t d, int32_t metric, int32_t device, uint64_t* out_handle);
 int32_t hipidx_destroy(uint64_t h);
 int32_t hipidx_add(uint64_t h, const float* x_host, int64_t n);
+/* `hipidx_add_dev` enqueues its re-tiling on `stream` and returns at once: `x_dev` must stay valid until that work has run.
+ * The library orders everything that reads the rows behind it -- a later add that re-allocates, `hipidx_save`,
+ * `hipidx_reconstruct` (host waits) and searches on any stream (device-side wait) -- so no caller-side synchronisation
+ * is needed between an add and the next call on the same handle. */
 int32_t hipidx_add_dev(uint64_t h, const float* x_dev, int64_t n, void* stream);
 int32_t hipidx_ntotal(uint64_t h, int64_t* out_n);
 int32_t hipidx_dim(uint64_t h, int32_t* out_d);

@@ -373,7 +373,9 @@ struct Bm25Index {
         int32_t rc;
         int max_slots = 1;
         for (int b = 0; b < nq; ++b) max_slots = std::max(max_slots, qoff[b + 1] - qoff[b]);
-        HR_CHECK_HIP(hipStreamSynchronize(st));   // the previous call's plan copy must have left the staging vectors
+        // the previous call's plan copy must have left the host staging vectors (whatever stream it ran on)
+        if (prev_ev_set) HR_CHECK_HIP(hipEventSynchronize(prev_ev));
+        else HR_CHECK_HIP(hipStreamSynchronize(st));
         plan_slots.assign((size_t)nq * max_slots, TileSlot{0, 0, -1});
         plan_nslots.assign((size_t)nq, 0);
         for (int b = 0; b < nq; ++b) {
@@ -442,8 +444,29 @@ struct Bm25Index {
         return HIPRAG_OK;
     }
 
+    // One workspace (ck / ci / theta / slots / acc) serves every call on this handle: a call on another stream than the
+    // previous one is ordered behind it on the device, so that two streams never share the workspace in time.
+    hipEvent_t prev_ev = nullptr;
+    bool prev_ev_set = false;
+    hipStream_t prev_stream = nullptr;
+
     int32_t search_dev(const uint32_t* terms, const int32_t* qoff, int nq, int k, double* o64p, float* o32p, i64* oidp,
                        hipStream_t st)
+    {
+        if (prev_ev_set && prev_stream != st) HR_CHECK_HIP(hipStreamWaitEvent(st, prev_ev, 0));
+        const int32_t rc = search_dev_impl(terms, qoff, nq, k, o64p, o32p, oidp, st);
+        if (rc) return rc;
+        if (!prev_ev) HR_CHECK_HIP(hipEventCreateWithFlags(&prev_ev, hipEventDisableTiming));
+        HR_CHECK_HIP(hipEventRecord(prev_ev, st));
+        prev_ev_set = true;
+        prev_stream = st;
+        return HIPRAG_OK;
+    }
+
+    ~Bm25Index() { if (prev_ev) (void)hipEventDestroy(prev_ev); }
+
+    int32_t search_dev_impl(const uint32_t* terms, const int32_t* qoff, int nq, int k, double* o64p, float* o32p, i64* oidp,
+                            hipStream_t st)
     {
         int32_t rc;
         int longest = 0;

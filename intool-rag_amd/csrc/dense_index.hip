@@ -1579,9 +1579,27 @@ struct DenseIndex {
     unsigned long long* fallback_counter() { return reinterpret_cast<unsigned long long*>(scalars.as<unsigned>() + 2); }
     unsigned long long* roundb_counter() { return reinterpret_cast<unsigned long long*>(scalars.as<unsigned>() + 4); }
 
+    // Ordering of `add` against everything else: add_dev enqueues its re-tiling kernels on the CALLER's stream, which may
+    // be a non-blocking stream the null stream does not wait for.  `add_ev` marks the last add; grow / save / reconstruct
+    // (null-stream copies) wait for it on the host, a search on another stream waits for it on the device.
+    hipEvent_t add_ev = nullptr;
+    bool add_pending = false;
+
+    int32_t wait_adds_host()
+    {
+        if (add_pending) { HR_CHECK_HIP(hipEventSynchronize(add_ev)); add_pending = false; }
+        return HIPRAG_OK;
+    }
+    int32_t wait_adds_stream(hipStream_t st)
+    {
+        if (add_pending) HR_CHECK_HIP(hipStreamWaitEvent(st, add_ev, 0));
+        return HIPRAG_OK;
+    }
+
     ~DenseIndex()
     {
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        if (add_ev) (void)hipEventDestroy(add_ev);
     }
 
     int32_t init()
@@ -1608,6 +1626,10 @@ struct DenseIndex {
     int32_t grow(int64_t need_blocks)
     {
         if (need_blocks <= cap_blocks) return HIPRAG_OK;
+        {   // the copies below run on the null stream: rows a previous add is still writing must have landed
+            const int32_t wrc = wait_adds_host();
+            if (wrc) return wrc;
+        }
         int64_t nc = cap_blocks == 0 ? need_blocks : std::max(need_blocks, cap_blocks + cap_blocks / 2);
         size_t xbytes = (size_t)nc * P * kPieceFloats * sizeof(float);
         size_t nbytes = (size_t)nc * kRowsPerBlock * sizeof(float);
@@ -1653,6 +1675,9 @@ struct DenseIndex {
         hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((nblk * (P / 2) * 64 + 255) / 256)), dim3(256), 0, st, x_dev, ntotal, n,
                            d, P / 2, xh.as<bf16x8_t>());
         HR_CHECK_HIP(hipGetLastError());
+        if (!add_ev) HR_CHECK_HIP(hipEventCreateWithFlags(&add_ev, hipEventDisableTiming));
+        HR_CHECK_HIP(hipEventRecord(add_ev, st));
+        add_pending = true;
         ntotal += n;
         update_launch_q();
         return HIPRAG_OK;
@@ -1921,6 +1946,10 @@ struct DenseIndex {
 
     int32_t begin_dev(const float* q_dev, int nq, int k, int slot, hipStream_t st)
     {
+        if (add_pending) {   // rows of the last add may still be in flight on another stream
+            if (hipEventQuery(add_ev) == hipSuccess) add_pending = false;
+            else { const int32_t wrc = wait_adds_stream(st); if (wrc) return wrc; }
+        }
         return metric == HIPRAG_METRIC_IP ? scan_pass<HIPRAG_METRIC_IP>(q_dev, nq, k, slot, st)
                                           : scan_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, st);
     }
@@ -2147,6 +2176,7 @@ int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host)
     DevBuf tmp;
     int32_t rc = tmp.reserve((size_t)ix->d * sizeof(float));
     if (rc) return rc;
+    if ((rc = ix->wait_adds_host())) return rc;
     const int64_t threads = (int64_t)ix->P * 2;
     hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr, ix->xb.as<float4>(), row,
                        (int64_t)1, ix->d, ix->P, tmp.as<float>());
@@ -2160,6 +2190,7 @@ int32_t hipidx_save(uint64_t h, const char* path)
 {
     GET_INDEX(h);
     HR_REQUIRE(path, "null path");
+    { const int32_t wrc = ix->wait_adds_host(); if (wrc) return wrc; }
     FILE* f = fopen(path, "wb");
     if (!f) { set_error("cannot open %s for writing", path); return HIPRAG_E_IO; }
     const char magic[8] = {'H', 'I', 'P', 'I', 'D', 'X', '0', '1'};

@@ -43,6 +43,25 @@ def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
     return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
 
 
+def agree_min(value: int, device: int, group=None) -> int:
+    """MIN of an integer over the ranks of `group` (one small all-reduce, at construction time only)."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=torch.device("cuda", device) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def check_same_shape(shape: tuple, group=None) -> None:
+    """Debug aid (HIPRAG_CHECK_SHAPES=1): every rank must enter a collective with the same (nq, k, ...)."""
+    import torch.distributed as dist
+    seen = [None] * dist.get_world_size(group)
+    dist.all_gather_object(seen, tuple(int(v) for v in shape), group=group)
+    if any(s != seen[0] for s in seen):
+        raise RuntimeError(f"ranks disagree on the batch shape of a sharded search: {seen}")
+
+
 class ShardedFlatIndex:
     def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None):
         import torch
@@ -65,12 +84,17 @@ class ShardedFlatIndex:
         self._slot_ended = [False] * N_SLOTS
         self._bufs = [dict() for _ in range(N_SLOTS)]
         self._scan_done = [torch.cuda.Event() for _ in range(N_SLOTS)]
+        self._max_pass = agree_min(local.launch_queries, local.device, group) if self.world > 1 else None
+        self._check_shapes = self.world > 1 and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
 
     @property
     def max_pass(self) -> int:
-        """Queries one search_begin takes = hipidx_launch_queries of the local index (it is sized by the shard: more
-        passes per launch on a smaller shard, so a launch lasts about as long whatever the shard size)."""
-        return self.local.launch_queries
+        """Queries one search_begin takes.  One GPU: hipidx_launch_queries of the local index (sized by the shard: more
+        passes per launch on a smaller shard, so a launch lasts about as long whatever the shard size).  Several ranks:
+        the MINIMUM of that over the group, agreed once at construction -- shards may differ by a 32-row block, and near a
+        rounding boundary of the sizing rule two ranks would otherwise cut the same batch into different numbers of
+        all-gathers and hang (or exchange mismatched shapes)."""
+        return self._max_pass if self._max_pass is not None else self.local.launch_queries
 
     def _buffers(self, slot: int, nq: int, k: int, dev):
         """Per-slot result buffers and events, created once per (nq, k): the steady state allocates nothing."""
@@ -99,6 +123,8 @@ class ShardedFlatIndex:
         nq = q.shape[0]
         if nq > self.max_pass:
             raise ValueError(f"search_begin takes at most {self.max_pass} queries; use search_device for larger batches")
+        if self._check_shapes:
+            check_same_shape((nq, k), self.group)
         slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
         c = self._buffers(slot, nq, k, q.device)

@@ -11,9 +11,11 @@ Behaviour mirrors HuggingFaceEmbeddingProvider (rag/providers/hf/embeddings.py:1
     normalize_embeddings=True (:34): CLS pooling + L2 normalisation happen on the GPU (csrc/encoder.hip pool_kernel)
   * dimension(): the model width (the reference probes it with a dummy encode, :37-38)
 
-Weights: HIP_ENCODER_WEIGHTS = path to a local safetensors file with XLM-R parameter names (BAAI/bge-m3 layout).
-Without it the provider builds SEEDED RANDOM weights of the configured architecture and logs a warning -- there is no
-checkpoint in an offline image; the GPU code path, shapes and cost are identical.
+Weights: HIP_ENCODER_WEIGHTS = path to a local safetensors file with XLM-R parameter names (BAAI/bge-m3 layout) and
+HIP_TOKENIZER_FILE = the model's tokenizer.json.  Without them the constructor RAISES, like the reference does when its
+model cannot be loaded (:26-29, :39-40).  HIP_ALLOW_SYNTHETIC=1 opts in to SEEDED RANDOM weights of the configured
+architecture and the hashing tokenizer (tests and benches: there is no checkpoint in an offline image; the GPU code
+path, shapes and cost are identical, the vectors are meaningless).
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ from typing import List, Optional
 from rag.config import config
 from rag.llm.embeddings.base import EmbeddingProvider
 from rag.logging import logger
-from rag.providers.hip.tokenizer import load_tokenizer
+from rag.providers.hip.tokenizer import allow_synthetic, load_tokenizer
 
 try:
     from hiprag import EncoderConfig, HipEncoder
@@ -65,9 +67,14 @@ class HipEmbeddingProvider(EmbeddingProvider):
             if weights:
                 from safetensors.torch import load_file
                 state = load_file(weights)
+            elif not allow_synthetic():
+                raise RuntimeError("HIP_ENCODER_WEIGHTS is not set: the hip embedding provider needs a local safetensors "
+                                   f"file of {self.model_name} (set HIP_ALLOW_SYNTHETIC=1 to run on seeded random weights)")
             else:
-                logger.warning("[EMBED] HIP_ENCODER_WEIGHTS not set: using seeded RANDOM weights of the "
-                               f"{self.model_name} architecture (no checkpoint is available offline)")
+                logger.warning("[EMBED] HIP_ALLOW_SYNTHETIC: seeded RANDOM weights of the "
+                               f"{self.model_name} architecture -- embeddings carry no meaning")
+            if tokenizer is None:
+                tokenizer = load_tokenizer(cfg.vocab)      # raises before any GPU memory is taken
             encoder = HipEncoder(cfg, state, device=config.HIP_DEVICE, seed=0)
         self.encoder = encoder
         self.tokenizer = tokenizer or load_tokenizer(encoder.cfg.vocab)

@@ -1,10 +1,12 @@
 """
 Tokenisation for the hip provider.
 
-Real deployments point HIP_TOKENIZER_FILE at BGE-M3's `tokenizer.json` (HuggingFace `tokenizers` format; the wheel is
-installed, the file is not shippable offline).  Without it the provider falls back to a SYNTHETIC hashing tokenizer --
-lower-cased whitespace tokens (the reference's only tokenisation, rag/agent/query_processor.py:26) hashed into the
-vocabulary -- which exercises the identical GPU path with meaningless ids; it logs a warning every time it is built.
+Deployments point HIP_TOKENIZER_FILE at BGE-M3's `tokenizer.json` (HuggingFace `tokenizers` format; the wheel is
+installed, the file is not shippable offline).  Without it `load_tokenizer` RAISES -- the reference raises when its model
+cannot be loaded (rag/providers/hf/embeddings.py:26-29,39-40) and a service that answers with meaningless vectors is worse
+than one that does not start.  HIP_ALLOW_SYNTHETIC=1 is the explicit opt-in (tests, benches) to a SYNTHETIC hashing
+tokenizer -- lower-cased whitespace tokens (the reference's only tokenisation, rag/agent/query_processor.py:26) hashed
+into the vocabulary -- which exercises the identical GPU path with meaningless ids.
 Sequences are `<s> tokens </s>` (ids 0 / 2), truncated to max_seq_len like sentence-transformers does.
 """
 from __future__ import annotations
@@ -22,7 +24,7 @@ class HashTokenizer:
     def __init__(self, vocab: int, bos: int = 0, eos: int = 2, first_id: int = 3):
         self.vocab, self.bos, self.eos, self.first = vocab, bos, eos, first_id
         self._memo = {}
-        logger.warning("[EMBED] no tokenizer file (HIP_TOKENIZER_FILE): using the SYNTHETIC hashing tokenizer")
+        logger.warning("[EMBED] SYNTHETIC hashing tokenizer in use: token ids carry no meaning")
 
     def _id(self, tok: str) -> int:
         hit = self._memo.get(tok)
@@ -66,8 +68,18 @@ class FileTokenizer:
         return [self.bos] + ia[:room] + [self.eos, self.eos] + ib + [self.eos]
 
 
+def allow_synthetic() -> bool:
+    """HIP_ALLOW_SYNTHETIC=1: random weights / the hashing tokenizer may stand in for missing model files."""
+    return os.getenv("HIP_ALLOW_SYNTHETIC", "").lower() in ("1", "true", "yes")
+
+
 def load_tokenizer(vocab: int, path: Optional[str] = None):
     path = path or os.getenv("HIP_TOKENIZER_FILE")
-    if path and os.path.exists(path):
+    if path:
+        if not os.path.exists(path):
+            raise RuntimeError(f"HIP_TOKENIZER_FILE={path!r} does not exist")
         return FileTokenizer(path)
+    if not allow_synthetic():
+        raise RuntimeError("HIP_TOKENIZER_FILE is not set: the hip provider needs the model's tokenizer.json "
+                           "(set HIP_ALLOW_SYNTHETIC=1 to run on the synthetic hashing tokenizer)")
     return HashTokenizer(vocab)

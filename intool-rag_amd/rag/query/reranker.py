@@ -16,7 +16,7 @@ from typing import List, Optional
 
 from rag.config import config
 from rag.logging import logger
-from rag.providers.hip.tokenizer import load_tokenizer
+from rag.providers.hip.tokenizer import allow_synthetic, load_tokenizer
 
 
 class RerankerError(Exception):
@@ -36,9 +36,17 @@ class CrossEncoderReranker:
             if weights:
                 from safetensors.torch import load_file
                 state = load_file(weights)
+            elif not allow_synthetic():
+                raise RerankerError("HIP_RERANKER_WEIGHTS is not set: the reranker needs a local safetensors file of "
+                                    f"{config.RERANKER_MODEL} (set HIP_ALLOW_SYNTHETIC=1 to run on seeded random weights)")
             else:
-                logger.warning("[RERANK] HIP_RERANKER_WEIGHTS not set: using seeded RANDOM weights of the "
-                               f"{config.RERANKER_MODEL} architecture")
+                logger.warning("[RERANK] HIP_ALLOW_SYNTHETIC: seeded RANDOM weights of the "
+                               f"{config.RERANKER_MODEL} architecture -- logits carry no meaning")
+            if tokenizer is None:
+                try:
+                    tokenizer = load_tokenizer(cfg.vocab)
+                except RuntimeError as e:
+                    raise RerankerError(str(e))
             encoder = HipEncoder(cfg, state, device=config.HIP_DEVICE, seed=1, with_head=True)
         if not encoder.has_head:
             raise RerankerError("the reranker needs an encoder with a classification head")

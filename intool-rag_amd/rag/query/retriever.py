@@ -10,8 +10,9 @@ PageLevelRetriever (rag/query/page_retriever.py:78-288) step for step:
 With hybrid search on (HYBRID_SEARCH_ENABLED, rag/config.py:43) the chunk list is the reciprocal-rank fusion of the
 dense list and a BM25 list over the same chunks (both depth top_chunks) -- the hybrid the reference's README.md:54-58
 describes but never implements; spec in DESIGN.md.  Fusion order decides which chunks survive; each chunk keeps its
-dense similarity as `score` (0.0 if only the sparse leg found it) so page scores stay on the reference's 0..1 scale,
-and metadata["rrf_score"] / ["bm25_score"] carry the rest.
+dense similarity as `score` so page scores stay on the reference's 0..1 scale; a chunk only the sparse leg found has
+score 0.0 and metadata["sparse_only"], which keeps it out of its page's mean (it still counts for the chunk boost);
+metadata["rrf_score"] / ["bm25_score"] carry the rest.
 
 Dense search, BM25 and RRF run in libhiprag.so; grouping and page ranking are a few dozen Python float operations and
 stay on the host exactly as the reference has them.
@@ -38,37 +39,14 @@ class RetrievedChunk:
 
 @dataclass
 class PageRanking:
-    """Page with ranking score and its chunks (page_retriever.py:35-75)."""
+    """Page with ranking score and its chunks (fields of page_retriever.py:35-41)."""
     page: int
     score: float
     chunks: List[RetrievedChunk]
     metadata: Dict[str, Any]
-
-    def get_context_text(self) -> str:
-        lines: List[str] = []
-        hierarchy = []
-        if self.metadata.get("chapter"):
-            hierarchy.append(f"Chapter {self.metadata['chapter']}")
-        if self.metadata.get("section"):
-            hierarchy.append(f"Section {self.metadata['section']}")
-        if self.metadata.get("title"):
-            hierarchy.append(f"{self.metadata['title']}")
-        if hierarchy:
-            lines += [f"[{' | '.join(hierarchy)}]", ""]
-        for chunk in self.chunks:
-            lines += [chunk.text, ""]
-        return "\n".join(lines).strip()
-
-    def to_citation(self) -> Dict[str, Any]:
-        return {
-            "page": self.page,
-            "chapter": self.metadata.get("chapter"),
-            "section": self.metadata.get("section"),
-            "subsection": self.metadata.get("subsection"),
-            "title": self.metadata.get("title"),
-            "source_file": self.metadata.get("source_filename"),
-            "relevance_score": round(self.score, 3),
-        }
+    # Prompt / citation formatting (the reference's get_context_text / to_citation, page_retriever.py:44-75) is string
+    # assembly after the hot path and out of scope (SURVEY 2 #9): callers that need it import the reference's own
+    # PageRanking -- INTEGRATION.md shows the one-line swap; the fields above are all it reads.
 
 
 def group_chunks_by_page(chunks: List[RetrievedChunk]) -> Dict[int, List[RetrievedChunk]]:
@@ -79,14 +57,31 @@ def group_chunks_by_page(chunks: List[RetrievedChunk]) -> Dict[int, List[Retriev
 
 
 def rank_pages(chunks_by_page: Dict[int, List[RetrievedChunk]]) -> List[PageRanking]:
+    """page score = mean(chunk scores) + min(0.05 n, 0.15), stable sort descending (page_retriever.py:166-213).
+    Hybrid mode only: a chunk that ONLY the BM25 leg found has no dense similarity; it counts towards n (extra lexical
+    evidence raises the page) but stays out of the mean -- averaging a 0.0 in would make a page rank LOWER for having
+    more evidence.  With hybrid off no chunk is sparse-only and this is the reference's arithmetic unchanged."""
     rankings = []
     for page_num, page_chunks in chunks_by_page.items():
-        avg_score = sum(c.score for c in page_chunks) / len(page_chunks)
+        scored = [c.score for c in page_chunks if not c.metadata.get("sparse_only")]
+        avg_score = sum(scored) / len(scored) if scored else 0.0
         chunk_boost = min(len(page_chunks) * 0.05, 0.15)
         rankings.append(PageRanking(page=page_num, score=avg_score + chunk_boost, chunks=page_chunks,
                                     metadata=page_chunks[0].metadata))
     rankings.sort(key=lambda r: r.score, reverse=True)       # stable: ties keep first-seen page order
     return rankings
+
+
+_META_KEYS = ("chapter", "section", "subsection", "title", "source_filename", "doc_id")    # page_retriever.py:129-136
+_HYBRID_KEYS = ("rrf_score", "bm25_score", "sparse_only")
+
+
+def _as_chunk(result: dict) -> RetrievedChunk:
+    """One enriched search row -> RetrievedChunk with the reference's defaults (page_retriever.py:123-139)."""
+    metadata: Dict[str, Any] = {key: result.get(key) for key in _META_KEYS}
+    metadata.update((key, result[key]) for key in _HYBRID_KEYS if key in result)
+    return RetrievedChunk(result.get("chunk_id", "unknown"), result.get("text", ""), result.get("score", 0),
+                          result.get("page", 0), metadata)
 
 
 class HybridRetriever:
@@ -110,21 +105,7 @@ class HybridRetriever:
         else:
             from rag.storage.hip_index import search_hip_by_vector
             search_results = await search_hip_by_vector(query_embedding, limit=self.top_chunks, project=project)
-        chunks = []
-        for result in search_results:
-            metadata = {
-                "chapter": result.get("chapter"),
-                "section": result.get("section"),
-                "subsection": result.get("subsection"),
-                "title": result.get("title"),
-                "source_filename": result.get("source_filename"),
-                "doc_id": result.get("doc_id"),
-            }
-            for extra in ("rrf_score", "bm25_score"):
-                if extra in result:
-                    metadata[extra] = result[extra]
-            chunks.append(RetrievedChunk(chunk_id=result.get("chunk_id", "unknown"), text=result.get("text", ""),
-                                         score=result.get("score", 0), page=result.get("page", 0), metadata=metadata))
+        chunks = [_as_chunk(result) for result in search_results]
         logger.info(f"Retrieved {len(chunks)} chunks")
         return chunks
 
@@ -157,6 +138,8 @@ class HybridRetriever:
             item["rrf_score"] = float(fs)
             if rid in bm25_of:
                 item["bm25_score"] = bm25_of[rid]
+            if rid not in dense_score:
+                item["sparse_only"] = True       # no dense similarity: rank_pages keeps it out of the page mean
             fused.append(item)
         return fused
 

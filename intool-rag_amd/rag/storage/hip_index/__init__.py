@@ -301,6 +301,8 @@ def clear_caches() -> None:
     with _LOCK:
         _INDEX_CACHE.clear()
         _CHUNK_CACHE.clear()
+    from rag.storage.hip_index.sparse import clear_sparse_cache
+    clear_sparse_cache()                 # postings are versioned by the chunk table they were built from
 
 
 __all__ = ["HipIndexReader", "create_hip_index", "save_hip_index", "search_hip_by_vector", "initialize_storage",

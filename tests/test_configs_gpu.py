@@ -1,0 +1,215 @@
+"""
+GPU parity at the BASELINE.json configurations the round-1 suite did not reach ("configs_untested"):
+
+  configs[2]  1M chunks hybrid: dense flat-IP top-50 + BM25 term-at-a-time top-50 + RRF -> top-10, ranks bit-exact
+              (BM25 at 1M documents = 62 document tiles, skip tables, the shared per-query bound theta)
+  configs[4]  the 24-layer, H = 1024 encoder (BGE-M3 / bge-reranker-v2-m3 architecture, rag/config.py:9,25) against the
+              fp32 oracle, and the embed -> hybrid -> rerank chain on one GPU with every stage checked against the oracle
+              fed the GPU's OWN previous-stage output (rag/providers/hf/embeddings.py:61-88 -> rag/storage/faiss_index.py:63-91
+              -> the build-defined rerank)
+
+configs[3] (10M rows x 8 GPUs) needs eight GPUs; its protocol is covered by tests/test_sharded_multiprocess.py and the
+emulated-shard tests.  Encoder tolerances here are MEASURED: the test prints the minimum cosine and the largest relative
+error it saw, and the asserted bounds sit a factor ~3 above those (see _ENC_* below).
+"""
+import numpy as np
+import pytest
+
+from oracle import encoder_oracle as eo
+from oracle import hybrid_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+# Measured on MI355X (r02, printed by the tests below), 24 layers x H 1024, bf16 operands / fp32 accumulation vs the fp32
+# oracle on the same bf16-rounded weights: min cosine 0.999946, i.e. ||gpu - ref|| <= 1.04e-2 on unit vectors; largest
+# element error 1.15e-3 (0.037 / sqrt(H); a unit vector's elements average 0.025); reranker logits within 5.6e-3.
+# Asserted bounds: 2 - 3 x those.
+_ENC_MIN_COS = 0.9998          # ||gpu - ref|| <= 2.0e-2
+_ENC_MAX_ABS = 0.1 / 32.0      # 0.1 / sqrt(H) = 3.1e-3 per element
+_RERANK_ATOL = 1.5e-2
+
+
+def _gpu_rows(torch, dev, c, chunk, d):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + c)
+    x = torch.randn((chunk, d), generator=g, device=dev, dtype=torch.float32)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def _zipf_postings_on_gpu(torch, dev, N, V, seed=777):
+    """SURVEY 8d postings drawn with torch's generator on the GPU (the numpy recipe takes minutes at 1M documents):
+    doc length 64 + (i * 2654435761 mod 256), term ids ~ Zipf(s = 1) over V by inverse CDF.  Returns host arrays."""
+    i = torch.arange(N, dtype=torch.int64, device=dev)
+    doc_len = 64 + (i * 2654435761) % 256
+    cdf = torch.cumsum(1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=dev), 0)
+    cdf /= cdf[-1].clone()
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = torch.rand(int(doc_len.sum().item()), generator=g, device=dev, dtype=torch.float64)
+    term = torch.clamp(torch.searchsorted(cdf, u), max=V - 1)
+    doc = torch.repeat_interleave(i, doc_len)
+    return doc.cpu().numpy(), term.cpu().numpy(), doc_len.cpu().numpy()
+
+
+def test_config2_1m_chunks_hybrid_bit_exact(gpu):
+    """configs[2] at full size.  Host builder == oracle builder (offsets, doc ids, fp32 impacts bit-equal); then 24 queries:
+    20 Zipf queries + one whose six lists are all long (>= 2048 postings in EVERY full one of the 62 document tiles: skip
+    tables everywhere), one of short lists only (every tile filters whole lists), one mixing both with a duplicated
+    term, one empty.  BM25 ids AND fp32 scores, dense top-50 ids, fused top-10 ids and scores: bit-exact vs the oracle."""
+    import torch
+    from hiprag import HipBM25, HipFlatIndex, build_postings, hybrid_search, rrf_fuse_device
+    dev = torch.device("cuda", 0)
+    N, V, d, depth, k, chunk = 1_000_000, 262_144, 1024, 50, 10, 125_000
+    doc, term, doc_len = _zipf_postings_on_gpu(torch, dev, N, V)
+    p = build_postings(doc, term, N, V, doc_len)                       # product-side builder (hiprag/sparse.py)
+    op = ho.build_postings_from_pairs(doc, term, N, V, doc_len)        # the oracle's
+    del doc, term
+    assert np.array_equal(p.offsets, op.offsets) and np.array_equal(p.doc_ids, op.doc_ids)
+    assert np.array_equal(p.impacts, op.impacts)
+    df = np.diff(p.offsets.astype(np.int64))
+    tile = 16384
+    ntiles = (N + tile - 1) // tile
+    assert ntiles == 62
+
+    def per_tile_min(t):
+        lo, hi = int(p.offsets[t]), int(p.offsets[t + 1])
+        return np.bincount(p.doc_ids[lo:hi] // tile, minlength=ntiles)[:N // tile].min()   # the 61 full tiles
+
+    cands = [t for t in range(16, 100, 3) if per_tile_min(t) >= 2048]
+    assert len(cands) >= 6, cands
+    long_terms = cands[::len(cands) // 6][:6]
+    short_terms = [int(t) for t in np.flatnonzero((df > 0) & (df < 2048))[[5, 500, 5000, 20000, 60000, -1]]]
+    queries = ho.synthetic_sparse_queries(20, n_terms=V, terms_per_query=6, seed=888, min_rank=16)
+    queries.append(np.asarray(long_terms, dtype=np.uint32))
+    queries.append(np.asarray(short_terms, dtype=np.uint32))
+    queries.append(np.asarray([long_terms[0], short_terms[0], long_terms[0], short_terms[1]], dtype=np.uint32))
+    queries.append(np.asarray([], dtype=np.uint32))
+    nq = len(queries)
+
+    bm25 = HipBM25(p)
+    s64, s32, sids = bm25.search_device(queries, depth)
+    torch.cuda.synchronize()
+    es, ei = ho.bm25_search(op, queries, depth)
+    assert np.array_equal(sids.cpu().numpy(), ei), np.argwhere((sids.cpu().numpy() != ei).any(1)).ravel()
+    assert np.array_equal(s32.cpu().numpy(), es)
+    assert bm25.stats()["postings_touched"] >= int(sum(df[int(t)] for q in queries for t in q))
+
+    index = HipFlatIndex(d, "ip")
+    host = []
+    for c in range(N // chunk):
+        x = _gpu_rows(torch, dev, c, chunk, d)
+        index.add_device(x)
+        host.append(x.cpu().numpy())
+    xh = np.concatenate(host)
+    del host
+    qd = torch.from_numpy(ho.synthetic_queries(nq, d, seed=4321)).to(dev)
+    _, _, dids = index.search_device(qd, depth)
+    torch.cuda.synchronize()
+    _, di = ho.flat_search(xh, qd.cpu().numpy(), depth, ho.METRIC_IP)
+    assert np.array_equal(dids.cpu().numpy(), di)
+
+    fs, fi = rrf_fuse_device(dids, sids, k)
+    torch.cuda.synchronize()
+    efs, efi = ho.rrf_fuse(di, ei, k)
+    assert np.array_equal(fi.cpu().numpy(), efi) and np.array_equal(fs.cpu().numpy(), efs)
+    # the one-call C-ABI fast path gives the same fused lists
+    hs, hi = hybrid_search(index, bm25, qd.cpu().numpy(), queries, depth=depth, k=k)
+    assert np.array_equal(hi, efi) and np.array_equal(hs, efs)
+    assert index.stats()["fallback_queries"] == 0
+
+
+@pytest.fixture(scope="module")
+def xlmr_large():
+    """24 layers x H 1024 x 16 heads x F 4096 (XLM-R large = BGE-M3 / bge-reranker-v2-m3) with a classification head, seeded
+    random weights; a 32k vocabulary keeps the host-side state small (the embedding table is a gather, not arithmetic)."""
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    cfg = EncoderConfig(vocab=32000, hidden=1024, layers=24, heads=16, ffn=4096, max_pos=600, max_seq_len=512)
+    sd = random_state(cfg, seed=24, with_head=True)
+    enc = HipEncoder(cfg, sd, with_head=True)
+    return cfg, eo.bf16_round_state(sd), enc
+
+
+def _tokens(rng, lens, vocab):
+    return [[0] + rng.integers(3, vocab, size=n - 2).tolist() + [2] for n in lens]
+
+
+def _report(name, got, ref):
+    cos = np.sum(got * ref, axis=1)
+    err = np.linalg.norm(got - ref, axis=1)
+    mx = np.abs(got - ref).max()
+    print(f"\n[{name}] min cosine {cos.min():.6f}  max ||gpu - ref|| {err.max():.3e}  max |delta| {mx:.3e}")
+    return float(cos.min()), float(mx)
+
+
+def test_encoder_24_layers_matches_fp32_oracle(gpu, xlmr_large):
+    """bf16 error compounds over 24 post-LN layers -- check it at the depth the real models have.
+    Four 64-token sequences on the small-batch (weight-streaming) GEMM path, the same four plus mixed lengths on the
+    tiled path; embeddings AND reranker logits."""
+    cfg, sd_r, enc = xlmr_large
+    rng = np.random.default_rng(2401)
+    toks = _tokens(rng, [64, 64, 64, 64], cfg.vocab)
+    ref = eo.embed_fp32(sd_r, toks, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    small = enc.encode_tokens(toks, batch_size=4).cpu().numpy()                   # 256 rows: gemm_skinny path
+    cmin, mx = _report("24 layers, 4 x 64 tokens, small-batch GEMMs", small, ref)
+    assert cmin >= _ENC_MIN_COS and mx <= _ENC_MAX_ABS
+    more = toks + _tokens(rng, [200, 17, 129, 384, 5, 96, 250, 33], cfg.vocab)   # 12 x 384 padded rows: tiled path
+    tiled = enc.encode_tokens(more, batch_size=16).cpu().numpy()
+    ref2 = eo.embed_fp32(sd_r, more[4:], cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    cmin, mx = _report("24 layers, mixed lengths, tiled GEMMs", tiled, np.concatenate([ref, ref2]))
+    assert cmin >= _ENC_MIN_COS and mx <= _ENC_MAX_ABS
+    assert np.allclose(np.linalg.norm(tiled, axis=1), 1.0, atol=1e-3)
+    logits = enc.score_tokens(more[:8], batch_size=8).cpu().numpy()
+    ref_l = eo.rerank_logits_fp32(sd_r, more[:8], cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    print(f"[24 layers, reranker head] max |logit delta| {np.abs(logits - ref_l).max():.3e}  (logit spread {np.ptp(ref_l):.3f})")
+    assert np.allclose(logits, ref_l, rtol=0, atol=_RERANK_ATOL)
+
+
+def test_config4_shape_embed_hybrid_rerank_stagewise(gpu, xlmr_large):
+    """configs[4] on one GPU: embed_batch(256 x 512 tokens) on the 24-layer encoder -> hybrid retrieve (dense top-50 +
+    BM25 top-50 + RRF top-10) -> cross-encoder rerank.  Every stage is compared with the oracle fed the GPU's output of
+    the stage before it, so no stage's tolerance leaks into the next one's check:
+      embed   4 of the 256 sequences against the fp32 oracle (sequences are independent: batching must not matter)
+      hybrid  the GPU's OWN 256 embeddings as queries: dense ids, BM25 ids + scores, fused ids + scores bit-exact
+      rerank  `<s> q </s></s> passage </s>` pairs of 2 queries x their fused top-10: logits within tolerance, and the
+              GPU's final order equals the oracle's wherever the oracle's logit gaps exceed the tolerance."""
+    import torch
+    from hiprag import HipBM25, HipFlatIndex, PostingsCSR, hybrid_search
+    cfg, sd_r, enc = xlmr_large
+    rng = np.random.default_rng(2404)
+    nseq, S = 256, 512
+    qtok = _tokens(rng, [S] * nseq, cfg.vocab)
+    emb = enc.encode_tokens(qtok, batch_size=256)                                  # one 256 x 512 forward
+    emb_h = emb.cpu().numpy()
+    pick = [0, 77, 130, 255]
+    ref = eo.embed_fp32(sd_r, [qtok[i] for i in pick], cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    cmin, mx = _report("configs[4] embed 256 x 512, 4 sequences checked", emb_h[pick], ref)
+    assert cmin >= _ENC_MIN_COS and mx <= _ENC_MAX_ABS
+    # ---- hybrid retrieval with the GPU's embeddings as the query vectors -------------------------------------------
+    n, depth, k = 50_000, 50, 10
+    x = ho.synthetic_vectors(n, cfg.hidden, seed=1234)
+    x[1000:1000 + nseq] = 0.6 * x[1000:1000 + nseq] + 0.8 * emb_h                  # every query has a planted neighbour
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    index = HipFlatIndex(cfg.hidden, "ip")
+    index.add(x)
+    p = ho.synthetic_postings(n, n_terms=8192, seed=777)
+    sq = ho.synthetic_sparse_queries(nseq, n_terms=8192, terms_per_query=6, seed=888, min_rank=16)
+    bm25 = HipBM25(PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts))
+    fs, fi = hybrid_search(index, bm25, emb_h, sq, depth=depth, k=k)
+    _, di = ho.flat_search(x, emb_h, depth, ho.METRIC_IP)
+    _, bi = ho.bm25_search(p, sq, depth)
+    efs, efi = ho.rrf_fuse(di, bi, k)
+    assert np.array_equal(fi, efi) and np.array_equal(fs, efs)
+    # ---- rerank the fused top-10 of two queries ---------------------------------------------------------------------
+    passages = {int(r): _tokens(rng, [int(rng.integers(20, 44))], cfg.vocab)[0][1:-1] for r in np.unique(fi[:2])}
+    for qi in range(2):
+        query = qtok[qi][1:25]
+        pairs = [[0] + query + [2, 2] + passages[int(r)] + [2] for r in fi[qi]]
+        got = enc.score_tokens(pairs, batch_size=16).cpu().numpy()
+        want = eo.rerank_logits_fp32(sd_r, pairs, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+        print(f"[configs[4] rerank q{qi}] max |logit delta| {np.abs(got - want).max():.3e}")
+        assert np.allclose(got, want, rtol=0, atol=_RERANK_ATOL)
+        order_g = sorted(range(k), key=lambda i: (-got[i], i))
+        order_o = sorted(range(k), key=lambda i: (-want[i], i))
+        for a, b in zip(order_g, order_o):
+            assert a == b or abs(want[a] - want[b]) <= 2 * _RERANK_ATOL
+    assert torch.isfinite(emb).all()

@@ -479,3 +479,53 @@ def test_near_ties_below_the_scan_resolution_stay_exact(gpu, monkeypatch, mode):
         _check(ix, x, q, k, metric)
         st = ix.stats()
         assert st["roundb_queries"] + st["fallback_queries"] >= 1
+
+
+@pytest.mark.parametrize("mode", ["bf16", "q64", "split", "f32"])
+def test_certificate_with_bf16_exact_inputs_and_ulp_level_ties(gpu, monkeypatch, mode):
+    """VERDICT r1 (certificate coverage hole).  With bf16-representable rows AND queries both truncation terms of the
+    certificate vanish (dq2 = dx2 = 0: integer-valued or pre-quantised embeddings) and eps collapses to the fp32
+    accumulation bound of the scan alone, (d_pad + 80) * 2^-24 * |q||x| -- an assumption about the MFMA's internal rounding
+    that no other test reaches.  Here 3000 rows at d = 1024 equal one base row except for the signs of 64 coordinates where
+    the query holds tiny (bf16-exact) values, so their exact scores differ by 1e-9 .. 4e-6 relative: from far below one fp32 ulp of
+    the score to a few dozen ulps, all inside what fp32 accumulation can blur.  Every scan mode must return the fp64
+    order (ids equal to the oracle's), for a unit-scale and a x4 query, both metrics."""
+    import torch
+    from hiprag import HipFlatIndex
+    monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
+    rng = np.random.default_rng(2026)
+    n, d, k = 12000, 1024, 20
+
+    def bf16_exact(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+    x = bf16_exact(rng.standard_normal((n, d)) / 32.0)
+    u = x[11].copy()
+    close = rng.choice(np.arange(100, n), size=3000, replace=False)
+    x[close] = u[None, :]
+    # ... differing from u only where the query is tiny, and only by SIGNS: every variant has the same norm, so the rows
+    # are near-ties under L2 as well as under inner product
+    x[close, :64] = bf16_exact(np.abs(rng.standard_normal(64)) / 32.0)[None, :] * rng.choice([-1.0, 1.0], size=(3000, 64))
+    x[close[:40]] = x[close[0]]                                              # and 40 exact duplicates: ties by id
+    q0 = u.copy()
+    q0[:64] = bf16_exact(rng.standard_normal(64) * 2.0 ** -17)
+    # a second, smaller family (150 variants of row 13): few enough groups within eps for round B to settle it, where the
+    # 3000-row family overflows round B and takes the exhaustive path
+    few = np.setdiff1d(np.arange(100, n), close)[::55][:150]             # spread out: (nearly) one per 16-row group
+    x[few] = x[13][None, :]
+    x[few, :64] = np.abs(x[13, :64])[None, :] * rng.choice([-1.0, 1.0], size=(150, 64))
+    q1 = x[13].copy()
+    q1[:64] = q0[:64]
+    q = np.stack([q0, 4.0 * q0, q1, -q0]).astype(np.float32)
+    assert np.array_equal(bf16_exact(x), x) and np.array_equal(bf16_exact(q), q)
+    s64 = ho.all_scores_f64(x[close], q0)
+    gaps = np.diff(np.sort(s64))
+    assert np.median(gaps[gaps > 0]) < 6e-8 * abs(s64).max()                 # typical neighbour gap below one fp32 ulp
+    for metric in (ho.METRIC_IP, ho.METRIC_L2):
+        ix = HipFlatIndex(d, metric)
+        ix.add(x)
+        _check(ix, x, q, k, metric)
+        _check(ix, x, q[:1], 50, metric)
+        st = ix.stats()
+        assert st["fallback_queries"] >= 1           # the scan alone cannot have ordered the large family ...
+        assert st["roundb_queries"] >= 1             # ... nor the small one, which round B settles

@@ -1,7 +1,9 @@
 """
 GPU parity of the MFMA encoder (hipenc_*) against the fp32 oracle on the SAME bf16-rounded weights.
-Tolerance (bf16 operands, fp32 accumulation, 2..24 layers): cosine >= 0.999 per embedding and max |diff| <= 2.5e-2 on the
-unit-norm outputs; reranker logits within 5e-2 absolute.  The retrieval ids computed FROM these embeddings are then
+Tolerance (bf16 operands, fp32 accumulation), derived from what the 24-layer H = 1024 case measures on MI355X
+(tests/test_configs_gpu.py prints it: min cosine 0.999946, largest element error 0.037 / sqrt(H)): cosine >= 0.9998 per
+embedding, i.e. ||gpu - ref|| <= 2e-2 on the unit-norm outputs, and max |diff| <= 0.1 / sqrt(H) per element; reranker
+logits within 1.5e-2 absolute.  Each case prints what it measured.  The retrieval ids computed FROM these embeddings are then
 exact (dense search is bit-exact for whatever vectors it is given).
 """
 import numpy as np
@@ -10,6 +12,9 @@ import pytest
 from oracle import encoder_oracle as eo
 
 pytestmark = pytest.mark.gpu
+MIN_COS = 0.9998
+MAX_ABS_SQRT_H = 0.1
+RERANK_ATOL = 1.5e-2
 
 
 def _tokens(rng, lens, vocab):
@@ -25,14 +30,18 @@ def _check(cfg, lens, seed, with_head=False, batch_size=256):
     toks = _tokens(rng, lens, cfg.vocab)
     got = enc.encode_tokens(toks, batch_size=batch_size).cpu().numpy()
     ref = eo.embed_fp32(eo.bf16_round_state(sd), toks, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    worst_cos, worst_abs = 1.0, 0.0
     for i, t in enumerate(toks):
         if len(t) == 0:
             assert np.all(got[i] == 0)
             continue
         cos = float(np.dot(got[i], ref[i]))
-        assert cos >= 0.999, (i, len(t), cos)
-        assert np.max(np.abs(got[i] - ref[i])) <= 2.5e-2
+        worst_cos, worst_abs = min(worst_cos, cos), max(worst_abs, float(np.max(np.abs(got[i] - ref[i]))))
+        assert cos >= MIN_COS, (i, len(t), cos)
+        assert np.max(np.abs(got[i] - ref[i])) <= MAX_ABS_SQRT_H / np.sqrt(cfg.hidden)
         assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-3
+    print(f"\n[encoder H={cfg.hidden} L={cfg.layers}] min cosine {worst_cos:.6f}  max |delta| {worst_abs:.3e} "
+          f"= {worst_abs * np.sqrt(cfg.hidden):.3f} / sqrt(H)")
     return enc, sd, toks, got, ref
 
 
@@ -81,8 +90,9 @@ def test_reranker_head_logits(gpu):
     enc, sd, toks, _, _ = _check(cfg, [20, 50, 7, 100], seed=7, with_head=True)
     got = enc.score_tokens(toks).cpu().numpy()
     ref = eo.rerank_logits_fp32(eo.bf16_round_state(sd), toks, cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
-    assert np.allclose(got, ref, atol=5e-2), (got, ref)
-    assert np.array_equal(np.argsort(-got), np.argsort(-ref)) or np.max(np.abs(np.sort(ref)[1:] - np.sort(ref)[:-1])) < 5e-2
+    print(f"\n[reranker head] max |logit delta| {np.abs(got - ref).max():.3e}")
+    assert np.allclose(got, ref, atol=RERANK_ATOL), (got, ref)
+    assert np.array_equal(np.argsort(-got), np.argsort(-ref)) or np.max(np.abs(np.sort(ref)[1:] - np.sort(ref)[:-1])) < 2 * RERANK_ATOL
 
 
 def test_bad_inputs_raise(gpu):

@@ -79,6 +79,16 @@ def _cpu_worker(rank, world, port, q_out):
         _, bi_full = ho.bm25_search(p, sq, depth)
         es_, ei_ = ho.rrf_fuse(di_full, bi_full, k)
         assert np.array_equal(fi_, ei_) and np.array_equal(fs_, es_)
+        # ranks whose shards differ by a block may derive different launch sizes: the agreed batch size is the minimum,
+        # and the debug check catches ranks entering a collective with different batch shapes
+        from hiprag.sharded import agree_min, check_same_shape
+        assert agree_min(448 + 64 * rank, 0) == 448
+        check_same_shape((nq, k))
+        try:
+            check_same_shape((nq + rank, k))
+            raise AssertionError("shape mismatch not detected")
+        except RuntimeError:
+            pass
         owned = [chunks_of_rank(32, world, r) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(32)) and all(o == list(range(o[0], o[-1] + 1)) for o in owned)
         q_out.put((rank, "ok"))
