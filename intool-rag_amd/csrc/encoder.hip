@@ -229,6 +229,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
     }
 }
 
+#include "gemm256.h"
+
 // ---------------------------------------------------------------------------------------------------------
 // Small-batch GEMM (the single-query latency path: embed_single / a handful of short texts, rows <= ~1024).
 // With 64..1024 activation rows the 128x128 tiles above leave 8..32 workgroups walking K serially (40 us for the F->H
@@ -699,6 +701,22 @@ struct Encoder {
                              // (HIPENC_SMALL_ROWS; measured crossover with the split-K tiled GEMM: 256 rows 1.72 vs 2.11 ms,
                              // 512 rows 2.37 vs 2.17 ms)
 
+    int n_cu = 256;
+    int use256 = 1;          // HIPENC_GEMM256=0 keeps every batch on the 128 x 128 kernel (A/B runs)
+
+    // the 256 x 256 persistent kernel: whole 256-tiles in M and N, an even number of k-tiles, and enough tiles to fill the CUs
+    bool big_ok(int M, int N, int K) const
+    {
+        return use256 && M % G2_T == 0 && N % G2_T == 0 && K % (2 * G2_BK) == 0 && (M / G2_T) * (N / G2_T) >= n_cu / 2;
+    }
+    template <int EPI>
+    void launch256(const GemmArgs& a, int Mpad, hipStream_t st) const
+    {
+        const int nbm = Mpad / G2_T, nbn = a.N / G2_T;
+        const int grid = std::min(nbm * nbn, n_cu);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn);
+    }
+
     // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
     static int skinny_split(int K) { return (K + 1023) / 1024; }
     static bool skinny_ok(int K) { const int sp = skinny_split(K); return K % (sp * 128) == 0; }
@@ -728,7 +746,10 @@ struct Encoder {
         const int H = cfg.hidden, F = cfg.ffn, heads = cfg.heads;
         const int S = ((max_len + 63) / 64) * 64;
         const int T = nseq * S;
-        const int M = ((T + BM - 1) / BM) * BM;
+        // big batches: 256 x 256 persistent tiles (gemm256.h) once the narrowest GEMM (N = H) fills every CU
+        const int M256 = ((T + G2_T - 1) / G2_T) * G2_T;
+        const bool big = big_ok(M256, H, H) && big_ok(M256, F, H) && big_ok(M256, H, F) && (M256 / G2_T) * (H / G2_T) >= n_cu;
+        const int M = big ? M256 : ((T + BM - 1) / BM) * BM;
         int32_t rc;
         if ((rc = tokens.reserve((size_t)nseq * S * 4))) return rc;
         if ((rc = lens.reserve((size_t)nseq * 4))) return rc;
@@ -748,7 +769,7 @@ struct Encoder {
             while (ks < 4 && (H / BN) * (M / BM) * ks < 512 && K % (ks * 2 * BK) == 0 && K / (ks * 2) >= 256) ks *= 2;
             return ks;
         };
-        const int osplit = small ? 1 : tile_split(H), dsplit = small ? 1 : tile_split(F);
+        const int osplit = (small || big) ? 1 : tile_split(H), dsplit = (small || big) ? 1 : tile_split(F);
         if ((rc = pre.reserve((size_t)M * H * 4 * (small ? fsplit : std::max(osplit, dsplit))))) return rc;
         if ((rc = ffn.reserve((size_t)M * F * 2))) return rc;
         // host staging: pad token rows to S with pad_id
@@ -778,6 +799,7 @@ struct Encoder {
             // rows >= T exist only as GEMM padding; the QKV scatter must not write them
             g.M = T;
             if (small) launch_skinny<EPI_QKV>(g, st);
+            else if (big) launch256<EPI_QKV>(g, M, st);
             else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
             hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
                                (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
@@ -791,6 +813,11 @@ struct Encoder {
                 hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                    (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), T, H, cfg.ln_eps, skinny_split(H),
                                    (const float*)L.bo, X);
+            } else if (big) {
+                launch256<EPI_RESID>(o, M, st);
+                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
+                                   (const float*)nullptr, (const bf16*)nullptr);
             } else if (osplit > 1) {
                 o.ksplit = osplit;
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * osplit), dim3(kGemmThreads), 0, st, o);
@@ -807,6 +834,7 @@ struct Encoder {
             f1.A = X; f1.W = (const bf16*)L.w1; f1.bias = (const float*)L.b1; f1.M = M; f1.N = F; f1.K = H;
             f1.out_bf16 = ffn.as<bf16>();
             if (small) { f1.M = T; launch_skinny<EPI_GELU>(f1, st); }
+            else if (big) launch256<EPI_GELU>(f1, M, st);
             else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, dim3((F / BN) * (M / BM)), dim3(kGemmThreads), 0, st, f1);
             GemmArgs f2{};
             f2.A = ffn.as<bf16>(); f2.W = (const bf16*)L.w2; f2.bias = (const float*)L.b2; f2.M = M; f2.N = H; f2.K = F;
@@ -817,6 +845,11 @@ struct Encoder {
                 hipLaunchKernelGGL(layernorm_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
                                    (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), T, H, cfg.ln_eps, fsplit,
                                    (const float*)L.b2, X);
+            } else if (big) {
+                launch256<EPI_RESID>(f2, M, st);
+                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
+                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
+                                   (const float*)nullptr, (const bf16*)nullptr);
             } else if (dsplit > 1) {
                 f2.ksplit = dsplit;
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * dsplit), dim3(kGemmThreads), 0, st, f2);
@@ -875,6 +908,11 @@ int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, i
     e->w = *weights;
     e->layers.assign(weights->layers, weights->layers + cfg->layers);
     if (const char* sr = std::getenv("HIPENC_SMALL_ROWS")) e->small_rows = std::atoi(sr);
+    if (const char* g2 = std::getenv("HIPENC_GEMM256")) e->use256 = std::atoi(g2);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cu = cus;
+    }
     for (const auto& L : e->layers)
         HR_REQUIRE(L.wqkv && L.bqkv && L.wo && L.bo && L.ln1_g && L.ln1_b && L.w1 && L.b1 && L.w2 && L.b2 && L.ln2_g && L.ln2_b,
                    "null layer weight pointer");
@@ -921,6 +959,47 @@ int32_t hipenc_score_pairs(uint64_t h, const int32_t* token_ids_host, const int3
                            int32_t max_len, float* out_logits_dev, void* stream)
 {
     return enc_run(h, token_ids_host, seq_lens_host, nseq, max_len, out_logits_dev, 1, stream);
+}
+
+int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_dev, int32_t M, int32_t N, int32_t K,
+                      int32_t epilogue, const void* resid_dev, void* out_dev, void* out_k_dev, void* out_vt_dev, int32_t S,
+                      int32_t heads, int32_t impl, void* stream)
+{
+    HR_REQUIRE(a_dev && w_dev && bias_dev && out_dev, "null argument");
+    HR_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0, "M, N multiples of 128 and K of 64");
+    HR_REQUIRE(epilogue >= 0 && epilogue <= 2, "epilogue: 0 = qkv, 1 = gelu, 2 = bias + residual");
+    HR_REQUIRE(impl >= 0 && impl <= 2, "impl: 0 = auto, 1 = 128 x 128 tiles, 2 = 256 x 256 persistent tiles");
+    GemmArgs g{};
+    g.A = (const bf16*)a_dev; g.W = (const bf16*)w_dev; g.bias = bias_dev; g.M = M; g.N = N; g.K = K;
+    if (epilogue == EPI_QKV) {
+        HR_REQUIRE(out_k_dev && out_vt_dev && S > 0 && heads > 0 && N == 3 * heads * 64 && M % S == 0 && S % 64 == 0,
+                   "qkv epilogue: N = 3 * heads * 64, M a multiple of S, S a multiple of 64");
+        g.q = (bf16*)out_dev; g.k = (bf16*)out_k_dev; g.vt = (bf16*)out_vt_dev; g.S = S; g.heads = heads; g.H = heads * 64;
+    } else if (epilogue == EPI_GELU) {
+        g.out_bf16 = (bf16*)out_dev;
+    } else {
+        HR_REQUIRE(resid_dev, "null residual");
+        g.resid = (const bf16*)resid_dev; g.out_f32 = (float*)out_dev;
+    }
+    int dev = 0, cus = 256;
+    HR_CHECK_HIP(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool can256 = M % G2_T == 0 && N % G2_T == 0 && K % (2 * G2_BK) == 0 && (epilogue != EPI_QKV || g.H % G2_T == 0);
+    HR_REQUIRE(impl != 2 || can256, "the 256-tile kernel needs M, N multiples of 256 and K of 128");
+    hipStream_t st = (hipStream_t)stream;
+    if (impl == 2 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
+        const int nbm = M / G2_T, nbn = N / G2_T, grid = std::min(nbm * nbn, cus);
+        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+    } else {
+        const dim3 grid((N / BN) * (M / BM));
+        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, grid, dim3(kGemmThreads), 0, st, g);
+        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, dim3(kGemmThreads), 0, st, g);
+        else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, grid, dim3(kGemmThreads), 0, st, g);
+    }
+    HR_CHECK_HIP(hipGetLastError());
+    return HIPRAG_OK;
 }
 
 int32_t hipenc_last_flops(uint64_t h, double* out_flops)

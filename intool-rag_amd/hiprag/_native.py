@@ -82,6 +82,8 @@ SIGNATURES = {
     "hipenc_forward": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p],
     "hipenc_score_pairs": [c_uint64, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p],
     "hipenc_last_flops": [c_uint64, f64p],
+    "hipenc_linear": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_int32, c_int32, c_int32, c_void_p],
     "hiprrf_fuse": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,
                     c_void_p],
     "hiprrf_fuse_dev": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,
