@@ -226,7 +226,8 @@ int32_t hipenc_score_pairs(uint64_t h, const int32_t* token_ids_host, const int3
                            int32_t max_len, float* out_logits_dev, void* stream);
 /* One linear layer of the encoder in isolation: C = A[M,K] * W[N,K]^T with the fused epilogue the encoder uses at that place
  * (0 = QKV: bias, q scaled by 1/8, head-major q / k into out / out_k and TRANSPOSED v into out_vt; 1 = bias + exact-erf GELU
- * -> bf16 [M,N]; 2 = bias + bf16 residual -> f32 [M,N]).  All pointers are device memory.  impl 0 picks the kernel the way
+ * -> bf16 [M,N]; 2 = bias + bf16 residual -> f32 [M,N]; 3 = the same sum rounded to bf16 [M,N], the pre-LayerNorm
+ * form of the big-batch path).  All pointers are device memory.  impl 0 picks the kernel the way
  * hipenc_forward does, 1 forces 128 x 128 tiles, 2 the persistent 256 x 256 tiles.  For kernel tests and benchmarks
  * (tests/test_encoder_gpu.py, tools/bench_gemm.py): the nn.Linear calls inside sentence-transformers' forward
  * (rag/providers/hf/embeddings.py:54,77) are what it stands for. */

@@ -42,7 +42,7 @@ constexpr int kGemmThreads = 256;
 
 __device__ __forceinline__ int swz_unit(int kc, int row, int rows) { return kc * rows + (row ^ (kc & 7)); }
 
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PART = 3 };
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PART = 3, EPI_RESID16 = 4 };   // RESID16: bf16 pre-LayerNorm rows (gemm256.h)
 
 struct GemmArgs {
     const bf16* A;      // [M, K] row-major
@@ -466,6 +466,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm over bf16 pre-LN rows (the big-batch path: gemm256's RESID16 epilogue) -> bf16; one wave per row, the row is
+// read once (16 B per lane per load, H <= 2048 -> <= 4 loads), statistics in fp32.
+__global__ __launch_bounds__(256) void layernorm16_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16* __restrict__ y, int M, int H,
+                                                         float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (size_t)row * H);
+    const int nvec = H >> 3;
+    bf16x8 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = xr[min(c, nvec - 1)];
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i * 64 + lane < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float a = (float)v[i][e] - mean; q += a * a; }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    bf16x8* yr = reinterpret_cast<bf16x8*>(y + (size_t)row * H);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            const float4 g0 = g4[2 * c], g1 = g4[2 * c + 1], b0 = b4[2 * c], b1 = b4[2 * c + 1];
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)v[i][e] - mean) * rstd * gg[e] + bb[e]);
+            yr[c] = o;
+        }
+    }
+}
+
 // K5: embeddings.  tokens [nseq, S] (pad beyond len), position id = s + pad_id + 1 for real tokens, pad_id for pads
 // (transformers' create_position_ids_from_input_ids with no interior pads).  One wave per token.
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ tokens, const int* __restrict__ lens, int S,
@@ -714,7 +763,7 @@ struct Encoder {
     {
         const int nbm = Mpad / G2_T, nbn = a.N / G2_T;
         const int grid = std::min(nbm * nbn, n_cu);
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn, 0, 0);
     }
 
     // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
@@ -814,10 +863,10 @@ struct Encoder {
                                    (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), T, H, cfg.ln_eps, skinny_split(H),
                                    (const float*)L.bo, X);
             } else if (big) {
-                launch256<EPI_RESID>(o, M, st);
-                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
-                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
-                                   (const float*)nullptr, (const bf16*)nullptr);
+                o.out_bf16 = pre.as<bf16>();      // bf16 pre-LayerNorm rows: half the store and LayerNorm-read bytes
+                launch256<EPI_RESID16>(o, M, st);
+                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
+                                   (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps);
             } else if (osplit > 1) {
                 o.ksplit = osplit;
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * osplit), dim3(kGemmThreads), 0, st, o);
@@ -846,10 +895,10 @@ struct Encoder {
                                    (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), T, H, cfg.ln_eps, fsplit,
                                    (const float*)L.b2, X);
             } else if (big) {
-                launch256<EPI_RESID>(f2, M, st);
-                hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)pre.as<float>(),
-                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps, 1,
-                                   (const float*)nullptr, (const bf16*)nullptr);
+                f2.out_bf16 = pre.as<bf16>();
+                launch256<EPI_RESID16>(f2, M, st);
+                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
+                                   (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps);
             } else if (dsplit > 1) {
                 f2.ksplit = dsplit;
                 hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PART>, dim3((H / BN) * (M / BM) * dsplit), dim3(kGemmThreads), 0, st, f2);
@@ -967,8 +1016,9 @@ int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_de
 {
     HR_REQUIRE(a_dev && w_dev && bias_dev && out_dev, "null argument");
     HR_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0, "M, N multiples of 128 and K of 64");
-    HR_REQUIRE(epilogue >= 0 && epilogue <= 2, "epilogue: 0 = qkv, 1 = gelu, 2 = bias + residual");
-    HR_REQUIRE(impl >= 0 && impl <= 2, "impl: 0 = auto, 1 = 128 x 128 tiles, 2 = 256 x 256 persistent tiles");
+    HR_REQUIRE(epilogue >= 0 && epilogue <= 3, "epilogue: 0 = qkv, 1 = gelu, 2 = bias + residual -> f32, 3 = bias + residual -> bf16");
+    HR_REQUIRE(epilogue != 3 || impl != 1, "the bf16 residual epilogue exists in the 256-tile kernel only");
+    HR_REQUIRE(impl >= 0 && impl <= 9, "impl: 0 = auto, 1 = 128 x 128 tiles, 2 = 256 x 256 persistent tiles (3 / 4: timing experiments)");
     GemmArgs g{};
     g.A = (const bf16*)a_dev; g.W = (const bf16*)w_dev; g.bias = bias_dev; g.M = M; g.N = N; g.K = K;
     if (epilogue == EPI_QKV) {
@@ -979,19 +1029,24 @@ int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_de
         g.out_bf16 = (bf16*)out_dev;
     } else {
         HR_REQUIRE(resid_dev, "null residual");
-        g.resid = (const bf16*)resid_dev; g.out_f32 = (float*)out_dev;
+        g.resid = (const bf16*)resid_dev; g.out_f32 = (float*)out_dev; g.out_bf16 = (bf16*)out_dev;
     }
     int dev = 0, cus = 256;
     HR_CHECK_HIP(hipGetDevice(&dev));
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool can256 = M % G2_T == 0 && N % G2_T == 0 && K % (2 * G2_BK) == 0 && (epilogue != EPI_QKV || g.H % G2_T == 0);
-    HR_REQUIRE(impl != 2 || can256, "the 256-tile kernel needs M, N multiples of 256 and K of 128");
+    HR_REQUIRE(impl < 2 || can256, "the 256-tile kernel needs M, N multiples of 256 and K of 128");
     hipStream_t st = (hipStream_t)stream;
-    if (impl == 2 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
+    HR_REQUIRE(epilogue != 3 || can256, "the bf16 residual epilogue needs M, N multiples of 256 and K of 128");
+    if (impl >= 2 || epilogue == 3 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
         const int nbm = M / G2_T, nbn = N / G2_T, grid = std::min(nbm * nbn, cus);
-        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
-        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
-        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        const int dbg = impl >= 3 ? impl - 2 : 0;   // bit 0: no staging, bit 1: no MFMAs, bit 2: no fragment reads
+        const char* sk = std::getenv("HIPENC_GEMM_SKEW");
+        const int skew = sk ? std::atoi(sk) : 0;
+        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
+        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
+        else if (epilogue == 3) hipLaunchKernelGGL(gemm256_kernel<EPI_RESID16>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
+        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
     } else {
         const dim3 grid((N / BN) * (M / BM));
         if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, grid, dim3(kGemmThreads), 0, st, g);

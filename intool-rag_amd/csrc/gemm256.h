@@ -5,11 +5,11 @@
 // LDS once per 16 k-tiles at K = 1024 -- 0.61-0.96 PFLOP/s on the encoder's shapes (r01).  This one follows the CDNA4
 // playbook for MFMA-bound loops at one workgroup per CU:
 //   * 8 waves = 2 groups of 4 (one wave of each group per SIMD) run the k-loop HALF A PHASE APART: while one group issues
-//     its LDS fragment reads and LDS-DMA staging (the "load" half-step), the other runs 16 MFMAs (the "compute" half-step);
+//     its LDS fragment reads and LDS-DMA staging (the "load" half-step), the other runs 32 MFMAs (the "compute" half-step);
 //     two raw s_barriers per phase keep them interleaved, so each SIMD's matrix pipe always has one wave feeding it.
 //   * a wave owns 128 x 64 outputs (acc = 128 registers): 24 ds_read_b128 per 64 MFMAs instead of 32 per 64.
-//   * staging never drains: half-slabs (16 KiB) of k-tile t+1 / t+2 are issued at fixed phases of k-tile t and waited for
-//     with ONE counted `s_waitcnt vmcnt(4)` per k-tile, 3-4 phases after their issue (hazard table below).
+//   * staging: the half-slabs (16 KiB) of k-tile t+1 are issued at fixed points of k-tile t and waited for with counted
+//     `s_waitcnt vmcnt(N)` two or more barrier intervals after their issue (hazard table below).
 //   * the workgroup is PERSISTENT: it walks output tiles (XCD-aware order) and the staging stream runs straight on into the
 //     next tile's first k-tiles, so the first-tile latency is paid once per workgroup, not once per tile.
 //   * the epilogue is wave-private: each wave transposes its accumulators through its own 4 KiB of LDS (no workgroup
@@ -23,13 +23,21 @@
 // (a second object makes hipcc drain vmcnt before every fragment read).  Half-slab image = 128 rows x 128 B, chunk kc of
 // row r at slot kc ^ (r & 7) (tile_unit): conflict-free for the DMA writes and the ds_read_b128 fragment reads.
 //
-// Hazards (V = k-tile being computed from buffer b = V & 1; "interval" = time between two consecutive barrier events;
-// group 0 loads in interval 8V+2ph and computes in 8V+2ph+1, group 1 half a phase later):
-//   reads of buffer b:  Q halves in load(ph0), load(ph1); P lo (group 0) / P hi (group 1) in load(ph0), load(ph2)
-//   ph0 of V issues   Q hi, P hi of V+1 -> buffer b^1  (last read by group 1 in load(ph2) of V-1, two barriers earlier)
-//   ph3 of V issues   Q lo, P lo of V+2 -> buffer b    (last read by group 0 in load(ph2) of V, done before its ph3)
-//   ph3 of V waits    vmcnt(4): everything but the 4 loads just issued has landed = all of V+1; every reader of V+1
-//                     (load(ph0) of V+1) has passed a barrier that every issuer reached after that wait.
+// Schedule: TWO phases per k-tile (32 MFMAs per wave each, four barrier events per k-tile -- a barrier round trip of the eight
+// waves costs ~100 cycles, measured with the MFMAs and the staging compiled out; four 16-MFMA phases spent a third of
+// their time in it):
+//   phase A  reads: all of the wave's Q fragments (8) + P row tiles 0-3 (8)       MFMAs: P tiles 0-3 x Q tiles 0-3
+//   phase B  reads: P row tiles 4-7 (8)                                           MFMAs: P tiles 4-7 x Q tiles 0-3
+// Hazards (V = k-tile being computed from buffer b = V & 1, cursor = V+1 staged into buffer b^1; "interval" = time between
+// two consecutive barrier events; group 0 runs load(A), compute(A), load(B), compute(B) in intervals 4V .. 4V+3, group 1 one
+// interval later):
+//   reads of buffer b^1 for V-1 completed: Q during interval 4V-2, P lo during 4V-1, P hi (group 1) during 4V
+//   load(A) of V issues Q lo, Q hi, P lo of V+1 (6 DMA instructions per wave); load(B) of V issues P hi of V+1 (2)
+//   W1  end of load(B) of V, after the 2 new ones: vmcnt(2) -> Q and P lo of V+1 have landed (issued two intervals ago)
+//   P hi of V+1 is read by group 1 only, first in its load(A) of V+1 (interval 4V+5):
+//   W2  group 1, end of compute(B) of V: vmcnt(0)            (its own portion, issued in interval 4V+3)
+//   W3  group 0, end of load(A) of V+1, after the 6 new ones: vmcnt(6)   (its portion, issued in interval 4V+2)
+//   every reader passes a barrier that every issuer reached after its wait.
 #pragma once
 
 constexpr int G2_T = 256, G2_BK = 64, G2_THREADS = 512;
@@ -45,13 +53,12 @@ constexpr int G2_LDS_BYTES = 2 * G2_SLAB + 8 * 4096;
     } while (0)
 
 template <int EPI>
-__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn)
+__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn, int dbg = 0, int skew = 0)
 {
     __shared__ __attribute__((aligned(16))) char lds[G2_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // wr: P half and wave group; wc: 64-row quarter of Q
-    const int r16 = lane & 15, kq = lane >> 4;
     const int nk = g.K / G2_BK;                   // even (launch condition)
     const int tiles = nbm * nbn;
     const int G = gridDim.x;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
     auto tile_swapped = [&](int n0) { return EPI == EPI_QKV && n0 >= 2 * g.H; };
 
     // ---- staging stream ------------------------------------------------------------------------------------------------
-    const int lane_g = (lane >> 3) * g.K + (((lane & 7) ^ (lane >> 3)) << 3);    // element offset of this lane's 16 B
+    int lane_g = (lane >> 3) * g.K + (((lane & 7) ^ (lane >> 3)) << 3);    // element offset of this lane's 16 B
     const bf16* sP = nullptr;      // row base (incl. k offset) of the cursor k-tile's P / Q operand
     const bf16* sQ = nullptr;
     int sL = vw, skt = 0;
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         }
     };
     auto issue_half = [&](const bf16* rowbase, int half, char* dst) {   // 16 KiB = 16 wave-instructions, 2 per wave
+        if (dbg & 1) return;   // timing experiments only (hipenc_linear impl 3): no staging, the MFMAs run on whatever LDS holds
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int inst = wave * 2 + u;
@@ -104,35 +112,47 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         }
     };
     if (!svalid) return;
+    // De-phase the workgroups: all of them start together and every tile takes the same time, so without this all 256 CUs
+    // reach their epilogues -- the only HBM-heavy part of the kernel -- at the same moment, and the store bursts queue up
+    // behind one another while HBM idles during the main loops.  A pseudo-random start delay of up to `skew` x 64 clocks
+    // (about one tile) spreads them out.
+    if (skew > 0) {
+        const unsigned ph = ((unsigned)vw * 2654435761u) >> 20;           // 12 bits
+        const int n = (int)(((unsigned long long)ph * (unsigned)skew) >> 12) / 127;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     cursor_tile();
-    // prologue: k-tile 0 whole, the lo halves of k-tile 1 (the state every later tile boundary is in as well)
+    // prologue: k-tile 0 whole (the state every later tile boundary is in as well: the cursor k-tile has landed)
     issue_half(sP, 0, lds + 0 * 16384);
     issue_half(sP, 1, lds + 1 * 16384);
     issue_half(sQ, 0, lds + 2 * 16384);
     issue_half(sQ, 1, lds + 3 * 16384);
     cursor_next();
-    if (svalid) {
-        issue_half(sQ, 0, lds + G2_SLAB + 2 * 16384);
-        issue_half(sP, 0, lds + G2_SLAB + 0 * 16384);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_BAR();
 
     // fragment read addresses: row r16 of a 16-row tile, 16-B chunk (4 ks + kq) ^ (r16 & 7); ks = 1 flips bit 2 of the chunk
-    const int loff0 = r16 * 128 + ((kq ^ (r16 & 7)) << 4);
-    const char* pA[2][2];   // [buffer][ks]
-    const char* pB[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            pA[b][ks] = lds + b * G2_SLAB + wr * 16384 + (loff0 ^ (ks << 6));
-            pB[b][ks] = lds + b * G2_SLAB + 32768 + wc * 8192 + (loff0 ^ (ks << 6));
-        }
+    int loff0 = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
 
     for (int L = vw; L < tiles; L += G) {
+        // the per-lane constants of the k-loop are RECOMPUTED at every tile start from an opaque copy of the lane id, so that
+        // nothing of the k-loop has to survive the epilogue in a register: a spilled constant comes back through a scratch
+        // load, hipcc answers that with `s_waitcnt vmcnt(0)` at its first use, and that use sits inside the k-loop
+        {
+            int lane_k = lane;
+            asm volatile("" : "+v"(lane_k));
+            lane_g = (lane_k >> 3) * g.K + (((lane_k & 7) ^ (lane_k >> 3)) << 3);
+            loff0 = (lane_k & 15) * 128 + (((lane_k >> 4) ^ (lane_k & 7)) << 4);
+        }
+        const char* pA[2][2];   // [buffer][ks]
+        const char* pB[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                pA[b][ks] = lds + b * G2_SLAB + wr * 16384 + (loff0 ^ (ks << 6));
+                pB[b][ks] = lds + b * G2_SLAB + 32768 + wc * 8192 + (loff0 ^ (ks << 6));
+            }
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -142,59 +162,51 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         if (wr == 1) G2_BAR();   // stagger: group 1 runs half a phase behind group 0
 
 #define G2_LDA(B, sub)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+    if (!(dbg & 4)) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
         a[i][ks] = *reinterpret_cast<const bf16x8*>(pA[B][ks] + ((sub) * 4 + i) * 2048)
-#define G2_LDB(B, dst, sub)                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-        dst[j][ks] = *reinterpret_cast<const bf16x8*>(pB[B][ks] + ((sub) * 2 + j) * 2048)
-#define G2_MFMA(as, bfrag, bs)                                                                  \
+#define G2_LDB(B)                                                                               \
+    if (!(dbg & 4)) _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+        b[j][ks] = *reinterpret_cast<const bf16x8*>(pB[B][ks] + j * 2048)
+#define G2_MFMA(as)                                                                             \
     do {                                                                                        \
+        if (dbg & 2) break;   /* timing experiments only: staging and barriers without the MFMAs */ \
         __builtin_amdgcn_s_setprio(1);                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
-                acc[(as) * 4 + i][(bs) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      \
-                    a[i][ks], bfrag[j][ks], acc[(as) * 4 + i][(bs) * 2 + j], 0, 0, 0);          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+                acc[(as) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[(as) * 4 + i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                          \
     } while (0)
 #define G2_KTILE(B)                                                                             \
     do {                                                                                        \
-        /* ph0: fragments b0, a0; stage the hi halves of the next k-tile into the other buffer */ \
-        G2_LDB(B, b0, 0);                                                                       \
+        /* phase A */                                                                           \
+        G2_LDB(B);                                                                              \
         G2_LDA(B, 0);                                                                           \
         if (svalid) {                                                                           \
+            issue_half(sQ, 0, lds + ((B) ^ 1) * G2_SLAB + 2 * 16384);                           \
             issue_half(sQ, 1, lds + ((B) ^ 1) * G2_SLAB + 3 * 16384);                           \
-            issue_half(sP, 1, lds + ((B) ^ 1) * G2_SLAB + 1 * 16384);                           \
-        }                                                                                       \
-        G2_BAR();                                                                               \
-        G2_MFMA(0, b0, 0);                                                                      \
-        G2_BAR();                                                                               \
-        /* ph1 */                                                                               \
-        G2_LDB(B, b1, 1);                                                                       \
-        G2_BAR();                                                                               \
-        G2_MFMA(0, b1, 1);                                                                      \
-        G2_BAR();                                                                               \
-        /* ph2 */                                                                               \
-        G2_LDA(B, 1);                                                                           \
-        G2_BAR();                                                                               \
-        G2_MFMA(1, b1, 1);                                                                      \
-        G2_BAR();                                                                               \
-        /* ph3: no fragment reads (b0 is still in registers); stage the lo halves of the k-tile after next into THIS */ \
-        /* buffer, then the one counted wait of the k-tile */                                   \
-        cursor_next();                                                                          \
-        if (svalid) {                                                                           \
-            issue_half(sQ, 0, lds + (B) * G2_SLAB + 2 * 16384);                                 \
-            issue_half(sP, 0, lds + (B) * G2_SLAB + 0 * 16384);                                 \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
-        } else {                                                                                \
+            issue_half(sP, 0, lds + ((B) ^ 1) * G2_SLAB + 0 * 16384);                           \
+            if (wr == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       /* W3 */        \
+        } else if (wr == 0) {                                                                   \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
         }                                                                                       \
         G2_BAR();                                                                               \
-        G2_MFMA(1, b0, 0);                                                                      \
+        G2_MFMA(0);                                                                             \
+        G2_BAR();                                                                               \
+        /* phase B */                                                                           \
+        G2_LDA(B, 1);                                                                           \
+        if (svalid) {                                                                           \
+            issue_half(sP, 1, lds + ((B) ^ 1) * G2_SLAB + 1 * 16384);                           \
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    /* W1 */        \
+            cursor_next();                                                                      \
+        }                                                                                       \
+        G2_BAR();                                                                               \
+        G2_MFMA(1);                                                                             \
+        if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           /* W2 */        \
         G2_BAR();                                                                               \
     } while (0)
 
         {
-            bf16x8 a[4][2], b0[2][2], b1[2][2];
+            bf16x8 a[4][2], b[4][2];
 #pragma unroll 1
             for (int kt = 0; kt < nk; kt += 2) {
                 G2_KTILE(0);
@@ -207,35 +219,93 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         int m0, n0;
         tile_origin(L, m0, n0);
         char* sc = lds + G2_SCRATCH + wave * 4096;
-        const int rrow = lane >> 4, rc = lane & 15;   // read-back: row 4t + rrow, 16-B chunk rc
+        // Every lane-derived quantity of the epilogue is recomputed here from an OPAQUE copy of the lane id: left to itself
+        // hipcc hoists the epilogue's address arithmetic out of the tile loop, keeps it live across the k-loop, spills, and
+        // then answers the reload with an `s_waitcnt vmcnt(0)` inside the k-loop -- which drains the LDS-DMA stream every
+        // k-tile.  (The k-loop itself needs 128 + 64 + ~20 registers.)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int r16 = lane_e & 15, kq = lane_e >> 4;
+        const int rrow = lane_e >> 4, rc = lane_e & 15;   // read-back: row 4t + rrow, 16-B chunk rc
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        if (EPI == EPI_RESID) {
-            // normal orientation: acc[i][j][r] = C[m0 + wc*64 + j*16 + r16][n0 + wr*128 + i*16 + 4kq + r]
+        if (EPI == EPI_RESID || EPI == EPI_RESID16) {
+            // normal orientation: acc[i][j][r] = C[m0 + wc*64 + j*16 + r16][n0 + wr*128 + i*16 + 4kq + r].
+            // Chunk (j, h2) = 16 rows x 64 columns of fp32 through the wave's scratch; read back as 8 consecutive columns per
+            // lane (two ds_read_b128), so the residual comes in 16-byte loads and the bf16 form leaves in 16-byte stores: 16
+            // loads + 16 (bf16) or 32 (fp32) stores per wave and tile -- the CU's vector-memory path takes ~70 clocks per
+            // wave-instruction, which is what an epilogue that all eight waves run at once is bound by.
+            // All global loads are inline asm with hand-counted waits: beside the LDS-DMA stream hipcc answers every ordinary
+            // load with `vmcnt(0)`, which here also waits for every store issued so far -- one memory round trip per chunk.
+            // Rows are never masked: M is a whole number of tiles for these two epilogues (launch condition).
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             const int mb = m0 + wc * 64, nb = n0 + wr * 128;
+            const int rb_row = lane_e >> 3, c8 = lane_e & 7;
+            u32x4 bq[2][2];                 // bias[nb + h2*64 + c8*8 + 0..7] as two float4
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float* bp = g.bias + nb + h2 * 64 + c8 * 8 + u * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[h2][u]) : "v"(bp) : "memory");
+                }
+            u32x4 rq[2][2][2];              // residual of two row groups j in flight: [j & 1][h2][t], 8 bf16 each
+            auto load_resid = [&](int j) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16* rp = g.resid + (size_t)(mb + j * 16 + t * 8 + rb_row) * g.N + nb + h2 * 64 + c8 * 8;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[j & 1][h2][t]) : "v"(rp) : "memory");
+                    }
+            };
+            load_resid(0);
+            load_resid(1);
+            constexpr int kStores = EPI == EPI_RESID16 ? 4 : 8;      // vector-memory stores per row group j
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // wait for the residual of group j: younger than it are the loads of group j+1 (4, if any) and the stores
+                // of group j-1 (if any); the bias loads are older than everything
+                if (j == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rq[0][0][0]), "+v"(rq[0][0][1]), "+v"(rq[0][1][0]), "+v"(rq[0][1][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]) :: "memory");
+                else if (j == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rq[1][0][0]), "+v"(rq[1][0][1]), "+v"(rq[1][1][0]), "+v"(rq[1][1][1]) : "i"(kStores) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rq[j & 1][0][0]), "+v"(rq[j & 1][0][1]), "+v"(rq[j & 1][1][0]), "+v"(rq[j & 1][1][1]) : "i"(kStores + 4) : "memory");
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
                         *reinterpret_cast<f32x4*>(sc + r16 * 256 + (((ii * 4 + kq) ^ r16) << 4)) = acc[h2 * 4 + ii][j];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int row = t * 4 + rrow;
-                        const f32x4 c = *reinterpret_cast<const f32x4*>(sc + row * 256 + ((rc ^ row) << 4));
-                        const int m = mb + j * 16 + row, n = nb + h2 * 64 + rc * 4;
-                        if (m < g.M) {
-                            const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-                            const bf16x4 rs = *reinterpret_cast<const bf16x4*>(g.resid + (size_t)m * g.N + n);
-                            float4 o;
-                            o.x = (c[0] + b.x) + (float)rs[0];
-                            o.y = (c[1] + b.y) + (float)rs[1];
-                            o.z = (c[2] + b.z) + (float)rs[2];
-                            o.w = (c[3] + b.w) + (float)rs[3];
-                            *reinterpret_cast<float4*>(g.out_f32 + (size_t)m * g.N + n) = o;
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = t * 8 + rb_row;
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sc + row * 256 + (((2 * c8) ^ row) << 4));
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sc + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+                        const u32x4 rr = rq[j & 1][h2][t];
+                        const u32x4 b0 = bq[h2][0], b1 = bq[h2][1];
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // bf16 pair e of the residual: low half = element 2e, high half = element 2e + 1
+                            const float r_lo = __uint_as_float(rr[e] << 16), r_hi = __uint_as_float(rr[e] & 0xffff0000u);
+                            const float c_lo = (2 * e < 4) ? c0[2 * e] : c1[2 * e - 4];
+                            const float c_hi = (2 * e + 1 < 4) ? c0[2 * e + 1] : c1[2 * e + 1 - 4];
+                            const float b_lo = __uint_as_float((2 * e < 4) ? b0[2 * e] : b1[2 * e - 4]);
+                            const float b_hi = __uint_as_float((2 * e + 1 < 4) ? b0[2 * e + 1] : b1[2 * e + 1 - 4]);
+                            o[2 * e] = (c_lo + b_lo) + r_lo;
+                            o[2 * e + 1] = (c_hi + b_hi) + r_hi;
+                        }
+                        const size_t at = (size_t)(mb + j * 16 + row) * g.N + nb + h2 * 64 + c8 * 8;
+                        if (EPI == EPI_RESID16) {
+                            bf16x8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
+                            *reinterpret_cast<bf16x8*>(g.out_bf16 + at) = v;
+                        } else {
+                            *reinterpret_cast<float4*>(g.out_f32 + at) = make_float4(o[0], o[1], o[2], o[3]);
+                            *reinterpret_cast<float4*>(g.out_f32 + at + 4) = make_float4(o[4], o[5], o[6], o[7]);
                         }
                     }
                 }
+                if (j + 2 < 4) load_resid(j + 2);
+            }
         } else if (EPI == EPI_QKV && tile_swapped(n0)) {
             // V third, swapped roles: acc[i][j][r] = C[m0 + wr*128 + i*16 + 4kq + r][n0 + wc*64 + j*16 + r16];
             // stored transposed [seq, head, d, S]: LDS rows = n (d), 128 consecutive m (s) per row
