@@ -699,6 +699,174 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K7, second form (the default): the same transposed flash attention on v_mfma_f32_32x32x16_bf16 with LDS-DMA staging.
+// What the first form spent its time on was not the matrix pipe (0.17 busy, r01) but ~550 vector instructions per 64-key
+// tile and wave: the key mask, the rescale of the output accumulators and their trips to and from the accumulator file on
+// EVERY tile, three operations per exponential, four cross-lane shuffles per tile, K / V tiles hauled global -> registers
+// -> LDS between two barriers.  Here:
+//   * a wave owns ONE tile of 32 queries; S^T = K Q^T puts a query on lanes q and q + 32, each holding 16 of a 32-key
+//     tile's scores: the row maximum needs one v_permlane32_swap per 64 keys, the row sum none at all until the end
+//     (every lane keeps its own partial sum; the rescale factor is the same for both halves);
+//   * the accumulators are rescaled only in tiles where some row maximum of the wave actually rose (wave-uniform branch;
+//     exact -- not a thresholded skip), the key mask only runs in the one tile that crosses the sequence length;
+//   * p = exp2(s * log2e - m * log2e): one fma + one v_exp per score;
+//   * K and V^T tiles (8 KiB each) arrive by LDS-DMA into a double buffer, swizzled on the source side
+//     (chunk ^ ((row >> 1) & 7): conflict-free for the b128 K-fragment reads AND the 8-byte V^T-fragment reads): one
+//     barrier per tile, the next tile's DMA in flight under this tile's MFMAs;
+//   * P^T never leaves registers: element j of lane half h of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the order
+//     the S^T accumulators already have -- and the V^T fragments are read in that order (two 8-byte runs);
+//   * the output tile goes through the (by then free) LDS buffers into 16-byte row-major stores.
+// grid (ceil(S/128), heads, nseq), 4 waves x 32 queries.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ __launch_bounds__(256, 2) void attention2_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                        const bf16* __restrict__ vt, const int* __restrict__ lens,
+                                                        bf16* __restrict__ ctx, int S, int heads, int H)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16384];   // [buffer][K tile 8 KiB | V^T tile 8 KiB]
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+    const int len = lens[seq];
+    if (q0 >= len) return;   // whole query tile is padding (ctx rows stay zero: memset by the caller)
+    const size_t hb = (size_t)seq * heads + head;
+    const bf16* qh = q + hb * S * 64;
+    const bf16* kh = k + hb * S * 64;
+    const bf16* vh = vt + hb * 64 * S;
+    const int nt = (len + 63) >> 6;
+
+    // staging: 16 wave-instructions per tile (8 rows of 128 B each), 4 per wave: waves 0,1 the K tile, waves 2,3 V^T
+    const int srow = lane >> 3, sslot = lane & 7;
+    auto issue = [&](int t, int buf) {
+        const int kt0 = t * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int inst = (wave & 1) * 4 + u;             // 0..7 inside the operand tile
+            const int row = inst * 8 + srow;                 // key (K) or d (V^T)
+            const int chunk = sslot ^ ((row >> 1) & 7);
+            const bf16* src = wave < 2 ? kh + (size_t)(kt0 + row) * 64 + chunk * 8 : vh + (size_t)row * S + kt0 + chunk * 8;
+            char* dst = lds + buf * 16384 + (wave < 2 ? 0 : 8192) + inst * 1024;
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query r32, half hh) holds Q[query][16 ks + 8 hh .. + 7], ks = 0..3
+    bf16x8 qf[4];
+    {
+        const int qi = min(q0 + wave * 32 + r32, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qi * 64 + ks * 16 + hh * 8);
+    }
+    f32x16 o[2];   // O^T tiles: d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hh, query r32
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float mrow = -INFINITY, lpart = 0.f;       // running max of the query's row; THIS lane's share of the row sum
+    const float LOG2E = 1.4426950408889634f;
+    const int swz = (r32 >> 1) & 7;            // swizzle of this lane's LDS row (row = r32 in every fragment read)
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1, kt0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t has landed
+        __builtin_amdgcn_s_barrier();                       // ... everyone's has; buffer buf ^ 1 is no longer being read
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
+        const char* kb = lds + buf * 16384;
+        const char* vb = kb + 8192;
+        // S^T tiles: sc[kt][r] = score(key kt0 + 32 kt + (r & 3) + 8 (r >> 2) + 4 hh, query r32)
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kt * 32 + r32) * 128 + (((2 * ks + hh) ^ swz) << 4));
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
+            }
+            sc[kt] = a;
+        }
+        if (kt0 + 64 > len) {   // the one tile that crosses the sequence length: padded keys never win
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * hh >= len) sc[kt][r] = -INFINITY;
+        }
+        float tmax = sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[1][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));           // the other half of the query's scores
+        if (__any(tmax > mrow)) {                            // some row maximum of this wave rose: rescale (exact)
+            const float mn = fmaxf(mrow, tmax);              // finite: key 0 of the first tile is always valid
+            const float alpha = __builtin_amdgcn_exp2f((mrow - mn) * LOG2E);
+            mrow = mn;
+            lpart *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        const float mL = mrow * LOG2E;
+        // P^T fragments: k-step s of key tile kt takes accumulator registers 8 s .. 8 s + 7
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][8 * s + j], LOG2E, -mL));
+                    lpart += p;
+                    pf[kt][s][j] = (bf16)p;
+                }
+        // O^T += V^T P^T: A fragment of d tile dt, key tile kt, k-step s = V^T[d = 32 dt + r32][keys 32 kt + 16 s + 4 hh + 0..3
+        // and 32 kt + 16 s + 8 + 4 hh + 0..3]: two 8-byte runs, 16-B chunk (4 kt + 2 s) resp. (4 kt + 2 s + 1), half hh
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vr = vb + (dt * 32 + r32) * 128 + hh * 8;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + (((4 * kt + 2 * s) ^ swz) << 4));
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (((4 * kt + 2 * s + 1) ^ swz) << 4));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s], o[dt], 0, 0, 0);
+                }
+    }
+    // row sum: the two halves of a query hold disjoint keys
+    const float inv = 1.f / (lpart + __shfl_xor(lpart, 32));
+    __builtin_amdgcn_s_barrier();    // every wave is done with the K / V^T buffers: they become the output staging area
+    char* ob = lds + wave * 4096;    // 32 queries x 128 B, 16-B chunk c of row q at c ^ (q & 7)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][4 * g4 + r] * inv);
+            const int d = 32 * dt + 8 * g4 + 4 * hh;       // 4 consecutive d
+            *reinterpret_cast<bf16x4*>(ob + r32 * 128 + (((d >> 3) ^ (r32 & 7)) << 4) + (d & 4) * 2) = v;
+        }
+    // read back: 8 lanes per query row (16 B each), 8 rows per pass, 4 passes
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + (lane >> 3), c = lane & 7;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ob + row * 128 + ((c ^ (row & 7)) << 4));
+        const int qi = q0 + wave * 32 + row;
+        if (qi < S) *reinterpret_cast<bf16x8*>(ctx + ((size_t)seq * S + qi) * H + head * 64 + c * 8) = v;
+    }
+}
+
 // K10a: CLS row (token 0 of each sequence) -> L2 normalise -> fp32 [nseq, H]; zero for empty sequences.
 __global__ __launch_bounds__(64) void pool_kernel(const bf16* __restrict__ x, const int* __restrict__ lens, int S, int H,
                                                  float* __restrict__ out, int normalize)
@@ -752,6 +920,7 @@ struct Encoder {
 
     int n_cu = 256;
     int use256 = 1;          // HIPENC_GEMM256=0 keeps every batch on the 128 x 128 kernel (A/B runs)
+    int attn_v1 = 0;         // HIPENC_ATTN_V1=1: the first attention kernel (16x16x32 MFMAs, register staging) for A/B runs
 
     // the 256 x 256 persistent kernel: whole 256-tiles in M and N, an even number of k-tiles, and enough tiles to fill the CUs
     bool big_ok(int M, int N, int K) const
@@ -850,9 +1019,14 @@ struct Encoder {
             if (small) launch_skinny<EPI_QKV>(g, st);
             else if (big) launch256<EPI_QKV>(g, M, st);
             else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
-            hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
-                               (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
-                               heads, H);
+            if (attn_v1)
+                hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
+                                   (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
+                                   heads, H);
+            else
+                hipLaunchKernelGGL(attention2_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
+                                   (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
+                                   heads, H);
             GemmArgs o{};
             o.A = ctx.as<bf16>(); o.W = (const bf16*)L.wo; o.bias = (const float*)L.bo; o.M = M; o.N = H; o.K = H;
             o.resid = X; o.out_f32 = pre.as<float>();
@@ -958,6 +1132,7 @@ int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, i
     e->layers.assign(weights->layers, weights->layers + cfg->layers);
     if (const char* sr = std::getenv("HIPENC_SMALL_ROWS")) e->small_rows = std::atoi(sr);
     if (const char* g2 = std::getenv("HIPENC_GEMM256")) e->use256 = std::atoi(g2);
+    if (const char* a1 = std::getenv("HIPENC_ATTN_V1")) e->attn_v1 = std::atoi(a1);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cu = cus;
