@@ -14,6 +14,16 @@ across the N ranks (STRONG scaling, total work fixed) and merged by one all-gath
 in flight so the latency-bound tail of a step (selection, fp64 re-score, exchange, merge) runs beside later scans.
 The library sizes a launch by the local row count (16 passes = 1024 queries per step at <= 250k rows per GPU).
 
+At N = 1 the same JSON line also carries `legs` (rank 0, after the headline section, each on the same GPU with its inputs
+resident in HBM; `--legs none` skips them, N > 1 never runs them):
+  legs.fp32_stream  the SURVEY 8(d)-priced scan: HIPRAG_SCAN_MODE=q64 streams the fp32 rows (N*d*4 bytes per pass) instead of
+                    the bf16 filter copy -- same exact results, the number the survey's byte accounting refers to
+  legs.hybrid       BASELINE configs[2]: 1M chunks, dense top-50 + BM25 term-at-a-time top-50 + RRF -> top-10; the BM25
+                    roofline is priced on the posting bytes the queries REQUEST (sum df * 8 B), not on SURVEY 8(d)'s
+                    accumulator passes, which the tiled kernel does not make
+  legs.encoder      BASELINE configs[4]'s embed stage: 256 x 512 tokens through the 24-layer XLM-R-large-shaped encoder
+                    (seeded random weights), flops / time / 2.5 PFLOP/s
+
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel = scan_bf16_kernel; achieved = algorithmic bytes per launch (passes * rows_local * d_pad * 2:
                the scan streams a 2-byte-per-element filter copy, the 4-byte rows are only touched by re-scoring;
@@ -51,6 +61,155 @@ def gen_chunk(torch, chunk_id: int, rows: int, dev):
     return x
 
 
+def _time_steps(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def run_legs(torch, args, dev, index, queries, legs):
+    """The single-GPU legs beside the headline line (module docstring).  Each leg frees what it allocated."""
+    from hiprag import HipBM25, HipFlatIndex, build_postings, rrf_fuse_device
+    from hiprag.sharded import ShardedFlatIndex
+    out = {}
+    n_rows = args.rows
+    chunk = CHUNK if n_rows == N_ROWS else max(1, n_rows // 32)
+    if "fp32" in legs:
+        # SURVEY 8(d)'s accounting (N*d*4 bytes per pass): the scan that streams the fp32 rows themselves
+        old = os.environ.get("HIPRAG_SCAN_MODE")
+        os.environ["HIPRAG_SCAN_MODE"] = "q64"
+        ix = HipFlatIndex(DIM, "ip", device=dev.index)
+        if old is None:
+            del os.environ["HIPRAG_SCAN_MODE"]
+        else:
+            os.environ["HIPRAG_SCAN_MODE"] = old
+        for c in range((n_rows + chunk - 1) // chunk):
+            ix.add_device(gen_chunk(torch, c, min(chunk, n_rows - c * chunk), dev))
+        sh = ShardedFlatIndex(ix, 0)
+        ix.reserve_search(TOPK)
+        batch = ix.launch_queries
+        passes = (batch + ix.pass_queries - 1) // ix.pass_queries
+        nb = N_QUERIES // batch
+        from collections import deque
+
+        def steps(n, first=0):
+            pending = deque()
+            for s in range(n):
+                b = (first + s) % nb
+                pending.append(sh.search_begin(queries[b * batch:(b + 1) * batch], TOPK))
+                if len(pending) >= 4:
+                    sh.search_end(pending.popleft())
+            while pending:
+                sh.search_end(pending.popleft())
+        steps(10)
+        torch.cuda.synchronize()
+        ix.enable_timing(1)
+        torch.cuda.synchronize()
+        n = max(20, args.steps // 4)
+        t0 = time.perf_counter()
+        steps(n, 10)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = ix.stats()
+        ix.enable_timing(False)
+        same = bool(torch.equal(ix.search_device(queries[:64], TOPK)[2], index.search_device(queries[:64], TOPK)[2]))
+        bpl = int(st["bytes_per_pass"]) * passes
+        ach = bpl / (st["avg_scan_ms"] * 1e-3) / 1e9
+        out["fp32_stream"] = {"workload": "configs[1] with HIPRAG_SCAN_MODE=q64: the scan streams the fp32 rows (N*d*4 B per pass)",
+                              "value": round(n * batch / el, 1), "unit": "queries/s", "steps": n, "queries_per_step": batch,
+                              "ms_per_step": round(el / n * 1e3, 4), "ids_equal_default_mode": same,
+                              "roofline": {"bound": "hbm", "kernel": "scan_split_kernel", "achieved": round(ach, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                           "bytes_per_launch": bpl, "passes_per_launch": passes,
+                                           "avg_launch_ms": round(float(st["avg_scan_ms"]), 5)}}
+        del sh, ix
+        torch.cuda.empty_cache()
+    if "hybrid" in legs:
+        N, V, depth, nq = n_rows, 262144, 50, 256
+        t0 = time.time()
+        i = torch.arange(N, dtype=torch.int64, device=dev)
+        doc_len = 64 + (i * 2654435761) % 256
+        cdf = torch.cumsum(1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=dev), 0)
+        cdf /= cdf[-1].clone()
+        gt = torch.Generator(device=dev)
+        gt.manual_seed(777)
+        u = torch.rand(int(doc_len.sum().item()), generator=gt, device=dev, dtype=torch.float64)
+        term = torch.clamp(torch.searchsorted(cdf, u), max=V - 1)
+        doc = torch.repeat_interleave(i, doc_len)
+        postings = build_postings(doc.cpu().numpy(), term.cpu().numpy(), N, V, doc_len.cpu().numpy())
+        del u, term, doc, i, cdf
+        build_s = time.time() - t0
+        bm25 = HipBM25(postings, device=dev.index)
+        rng = np.random.default_rng(888)
+        w = 1.0 / np.arange(17, V + 1, dtype=np.float64)           # 6 distinct terms per query, Zipf restricted to ranks >= 16
+        cdfq = np.cumsum(w) / w.sum()
+        sq = []
+        for _ in range(nq):
+            t = []
+            while len(t) < 6:
+                c = int(min(np.searchsorted(cdfq, rng.random()), len(cdfq) - 1)) + 16
+                if c not in t:
+                    t.append(c)
+            sq.append(np.asarray(t, dtype=np.uint32))
+        qd = queries[:nq]
+        b0 = bm25.stats()
+        t_sparse = _time_steps(torch, lambda: bm25.search_device(sq, depth), 5, 2)
+        b1 = bm25.stats()
+        t_dense = _time_steps(torch, lambda: index.search_device(qd, depth), 5, 2)
+        dl = index.search_device(qd, depth)
+        sl = bm25.search_device(sq, depth)
+        t_fuse = _time_steps(torch, lambda: rrf_fuse_device(dl[2], sl[2], TOPK), 20, 3)
+
+        def hybrid():
+            a = index.search_device(qd, depth)
+            b = bm25.search_device(sq, depth)
+            return rrf_fuse_device(a[2], b[2], TOPK)
+        t_all = _time_steps(torch, hybrid, 5, 2)
+        calls = 7
+        post_per_q = (b1["postings_touched"] - b0["postings_touched"]) / (calls * nq)
+        posting_gbs = post_per_q * 8 * (nq / t_sparse) / 1e9
+        fetch = None
+        prof = os.path.join(REPO, "profiles", "r01_pmc_hybrid_fetch.json")
+        if os.path.exists(prof):
+            fetch = {"source": "profiles/r01_pmc_hybrid_fetch.json (rocprofv3 --pmc FETCH_SIZE of the round-1 kernel; not collected "
+                               "by this run)", "summary": json.load(open(prof)).get("kernels", {}).get("taat_tile_kernel")}
+        out["hybrid"] = {"workload": f"configs[2]: {N} chunks, dense IP top-{depth} + BM25 TAAT top-{depth} + RRF -> top-{TOPK}, {nq} queries per call",
+                         "value": round(nq / t_all, 1), "unit": "queries/s", "dense_top50_qps": round(nq / t_dense, 1),
+                         "bm25_qps": round(nq / t_sparse, 1), "rrf_qps": round(nq / t_fuse, 1),
+                         "postings": int(postings.offsets[-1]), "postings_per_query": int(post_per_q),
+                         "postings_build_s": round(build_s, 1),
+                         "bm25_roofline": {"bound": "hbm", "kernel": "taat_tile_kernel", "achieved": round(posting_gbs, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(posting_gbs / HBM_PEAK_GBS, 4),
+                                           "bytes": "posting bytes the queries request (sum of df x 8 B); most of them are served by L2 "
+                                                    "because frequent terms recur across a batch",
+                                           "traffic_from_profile": fetch}}
+        del bm25, postings
+        torch.cuda.empty_cache()
+    if "encoder" in legs:
+        from hiprag import EncoderConfig, HipEncoder
+        cfg = EncoderConfig()                                        # XLM-R large: 24 x [H 1024, 16 heads, F 4096], vocab 250002
+        enc = HipEncoder(cfg, seed=0, device=dev.index)
+        rng = np.random.default_rng(0)
+        bs, seq = 256, 512
+        toks = [[0] + rng.integers(3, cfg.vocab, size=seq - 2).tolist() + [2] for _ in range(bs)]
+        dt = _time_steps(torch, lambda: enc.encode_tokens(toks, batch_size=bs), 3, 1)
+        flops = enc.last_flops()
+        out["encoder"] = {"workload": "configs[4] embed stage: embed_batch(256 x 512 tokens), XLM-R-large shape, seeded random weights",
+                          "value": round(bs * seq / dt, 1), "unit": "tokens/s", "ms_per_batch": round(dt * 1e3, 2),
+                          "flops_per_batch": flops,
+                          "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                       "frac": round(flops / dt / 2.5e15, 4),
+                                       "note": "whole forward by wall time (host tokens in, embeddings on the GPU out)"}}
+        del enc
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +218,7 @@ def main():
     ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--legs", default="fp32,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
@@ -166,16 +326,22 @@ def main():
     else:
         scan_ms, wall_ms = float(st["avg_scan_ms"]), float(st["avg_scan_wall_ms"])
 
-    # ---- p50 latency of single queries through the host boundary (python -> C-ABI -> sync) -----------
-    lat = []
+    # ---- p50 latency of single queries: (a) through the host boundary -- hipidx_search with HOST arrays in and out: H2D of
+    # the query, scan, tails, D2H of the result, sync -- which is what BASELINE.md / DESIGN.md quote; (b) device-resident -----
+    lat, lat_dev = [], []
+    q_host = queries[:120].cpu().numpy()
     for i in range(120):
+        t1 = time.perf_counter()
+        index.search(q_host[i:i + 1], TOPK)
+        lat.append((time.perf_counter() - t1) * 1e3)
         qi = queries[i:i + 1]
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         sharded.search_device(qi, TOPK)
         torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
+        lat_dev.append((time.perf_counter() - t1) * 1e3)
     lat = np.sort(np.asarray(lat[20:]))
+    lat_dev = np.sort(np.asarray(lat_dev[20:]))
 
     if rank != 0:
         if world > 1:
@@ -209,6 +375,8 @@ def main():
                    "steps_in_flight": IN_FLIGHT},
         "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
+        "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),
+        "latency_path": "hipidx_search: host query in, host results out (H2D + scan + tails + D2H + sync) on the local shard",
         "fallback_queries": int(st["fallback_queries"]),
         "build_s": round(build_s, 2),
         "roofline": {"bound": "hbm", "kernel": "scan_bf16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -223,18 +391,25 @@ def main():
         from oracle import hybrid_oracle as ho
         xh = np.concatenate(host_rows, axis=0)
         del host_rows
-        nsample = 24
-        qh = queries[:nsample].cpu().numpy()
-        ho.flat_search_f32_faithful(xh[:20000], qh[:2], TOPK, ho.METRIC_IP)   # warm the pages / code
+        nwarm, nsample = 20, 200                                              # 20 warm-up + 200 timed queries
+        qh = queries[nwarm:nwarm + nsample].cpu().numpy()
+        ho.flat_search_f32_faithful(xh, queries[:nwarm].cpu().numpy(), TOPK, ho.METRIC_IP)
+        lat_cpu = []
+        ci = np.empty((nsample, TOPK), dtype=np.int64)
         t1 = time.perf_counter()
-        cs, ci = ho.flat_search_f32_faithful(xh, qh, TOPK, ho.METRIC_IP)
+        for i in range(nsample):                                              # one query per call, like the reference (faiss_index.py:81-83)
+            t2 = time.perf_counter()
+            ci[i] = ho.flat_search_f32_faithful(xh, qh[i:i + 1], TOPK, ho.METRIC_IP)[1][0]
+            lat_cpu.append(time.perf_counter() - t2)
         cpu_s = time.perf_counter() - t1
-        g64, g32, gi = index.search_device(queries[:nsample], TOPK)
+        lat_cpu = np.sort(np.asarray(lat_cpu)) * 1e3
+        g64, g32, gi = index.search_device(queries[nwarm:nwarm + nsample], TOPK)
         torch.cuda.synchronize()
         agree = bool(np.array_equal(gi.cpu().numpy(), ci))
         out["cpu_baseline"] = {"value": round(nsample / cpu_s, 3), "unit": "queries/s", "cores": 1, "kind": "port",
-                               "sample": f"{nsample} queries x full {n_rows}x{DIM} index, one query per call, 1 thread, "
-                                         f"fp32 C restatement of IndexFlat search (FAISS itself is not installed)",
+                               "sample": f"{nwarm} warm-up + {nsample} timed queries x full {n_rows}x{DIM} index, one query per call, "
+                                         f"1 thread, fp32 C restatement of IndexFlat search (FAISS itself is not installed)",
+                               "p50_ms": round(float(lat_cpu[nsample // 2]), 2), "p99_ms": round(float(lat_cpu[int(nsample * 0.99) - 1]), 2),
                                "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
                                "ids_equal_gpu": agree}
         # SURVEY 8d row (ii), reported beside the faithful port: best-effort CPU -- one batched X @ Q^T on numpy's BLAS
@@ -261,8 +436,14 @@ def main():
     if world == 1 and n_rows == N_ROWS and os.path.exists(pmc):
         with open(pmc) as f:
             p = json.load(f)
-        out["roofline"]["traffic"] = int(p["traffic_bytes_per_launch"])
-        out["roofline"]["traffic_source"] = "profiles/r01_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        # NOT measured in this run: counters cannot be read from inside the process.  `traffic` stays null; the number of the
+        # committed PMC summary (same binary path, same workload) travels under a key that says where it comes from.
+        out["roofline"]["traffic_from_profile"] = {"bytes_per_launch": int(p["traffic_bytes_per_launch"]),
+                                                   "source": "profiles/r01_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                             "WRITE_SIZE, separate passes; not collected by this run)"}
+    if world == 1 and args.legs != "none":
+        del sharded
+        out["legs"] = run_legs(torch, args, dev, index, queries, [v.strip() for v in args.legs.split(",") if v.strip()])
     print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -770,6 +770,12 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const bf16* __restri
     float mrow = -INFINITY, lpart = 0.f;       // running max of the query's row; THIS lane's share of the row sum
     const float LOG2E = 1.4426950408889634f;
     const int swz = (r32 >> 1) & 7;            // swizzle of this lane's LDS row (row = r32 in every fragment read)
+    // 16 registers of zeros that stay zeros: the first MFMA of every score tile takes them as its C operand (D != C), which
+    // saves the 32 v_mov per tile that zeroing two accumulator tiles costs; opaque, or hipcc re-materialises them
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    asm volatile("" : "+v"(zero16));
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1, kt0 = t * 64;
@@ -782,15 +788,11 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const bf16* __restri
         f32x16 sc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            f32x16 a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kt * 32 + r32) * 128 + (((2 * ks + hh) ^ swz) << 4));
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sc[kt], 0, 0, 0);
             }
-            sc[kt] = a;
         }
         if (kt0 + 64 > len) {   // the one tile that crosses the sequence length: padded keys never win
 #pragma unroll
