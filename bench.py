@@ -343,6 +343,12 @@ def main():
     lat = np.sort(np.asarray(lat[20:]))
     lat_dev = np.sort(np.asarray(lat_dev[20:]))
 
+    rows_local = [int(index.ntotal)]
+    if world > 1:      # what every rank holds, as seen by the collective: lets a reader check that N ranks really took part
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, int(index.ntotal), int(row_lo), int(sharded.max_pass)))
+        rows_local = [v[1] for v in sorted(seen)]
+        assert sum(rows_local) == n_rows and all(v[3] == sharded.max_pass for v in seen), seen
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -372,7 +378,9 @@ def main():
                    "queries_per_pass": index.pass_queries,
                    "sharding": f"rows/{world}" if world > 1 else "none",
                    "exchange": f"1 all-gather of [2,{BATCH},{TOPK}] int64 per step" if world > 1 else "none",
-                   "steps_in_flight": IN_FLIGHT},
+                   "steps_in_flight": IN_FLIGHT, "world": world, "rows_local": rows_local,
+                   "backend": (args.backend if world > 1 else "none"),
+                   "allgather_payload_bytes_per_rank": (2 * BATCH * TOPK * 8 if world > 1 else 0)},
         "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),

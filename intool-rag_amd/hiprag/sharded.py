@@ -261,27 +261,129 @@ def _merge_and_fuse(gathered, depth: int, k: int, metric, c: float, w_dense: flo
 
 
 class ShardedHybrid:
+    """Row-sharded hybrid search with the same pipeline as ShardedFlatIndex: the dense scan of a batch is enqueued on the
+    caller's stream; its finish, the BM25 leg, the ONE all-gather of both packed partial lists (async) and -- in
+    search_end -- the two global merges and the fusion run on the stream of one of eight slots, on pre-allocated
+    per-slot buffers.  Batches larger than the agreed launch size are cut into pipelined pieces."""
+
     def __init__(self, dense: HipFlatIndex, bm25, row_lo: int = 0, group=None):
+        import torch
         import torch.distributed as dist
         self.dense, self.bm25, self.group = dense, bm25, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dense.set_id_base(row_lo)
         bm25.set_id_base(row_lo)
+        if self.world > 1 and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+            dense.set_spare_cus(8)          # room for the all-gather kernel beside the next scan (ShardedFlatIndex)
+        self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.world > 1 else None
+        self._check_shapes = self.world > 1 and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
+        self.side = [torch.cuda.Stream(device=dense.device) for _ in range(N_SLOTS)]
+        self._side_ptr = [st.cuda_stream for st in self.side]
+        self._slot = 0
+        self._used = [False] * N_SLOTS
+        self._ended = [True] * N_SLOTS
+        self._bufs = [dict() for _ in range(N_SLOTS)]
+
+    @property
+    def max_pass(self) -> int:
+        return self._max_pass if self._max_pass is not None else self.dense.launch_queries
+
+    def _buffers(self, slot: int, nq: int, depth: int, k: int, dev):
+        import torch
+        key = (nq, depth, k)
+        c = self._bufs[slot]
+        if c.get("key") != key:
+            if self._used[slot]:
+                self.side[slot].synchronize()
+            c.clear()
+            c["key"] = key
+            c["pack"] = torch.empty((2, 2, nq, depth), dtype=torch.int64, device=dev)       # [leg, {score bits, ids}, nq, depth]
+            c["s32"] = torch.empty((2, nq, depth), dtype=torch.float32, device=dev)
+            c["gathered"] = (torch.empty((self.world, 2, 2, nq, depth), dtype=torch.int64, device=dev)
+                             if self.world > 1 else None)
+            c["legs"] = [(torch.empty((nq, depth), dtype=torch.float64, device=dev),
+                          torch.empty((nq, depth), dtype=torch.float32, device=dev),
+                          torch.empty((nq, depth), dtype=torch.int64, device=dev)) for _ in range(2)]
+            c["fused"] = (torch.empty((nq, k), dtype=torch.float32, device=dev),
+                          torch.empty((nq, k), dtype=torch.int64, device=dev))
+            c["scanned"], c["fin"] = torch.cuda.Event(), torch.cuda.Event()
+        return c
+
+    def search_begin(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
+                     w_sparse: float = 1.0):
+        """q: float32 CUDA tensor [nq <= max_pass, d], the same on every rank, valid until search_end; sparse_queries: nq
+        term-id lists.  Returns a ticket; the tensors search_end hands out belong to the slot (reused 8 batches later)."""
+        import torch
+        nq = q.shape[0]
+        if nq > self.max_pass or len(sparse_queries) != nq:
+            raise ValueError(f"search_begin takes at most {self.max_pass} queries with one term list each")
+        if self._check_shapes:
+            check_same_shape((nq, depth, k), self.group)
+        slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
+        main = torch.cuda.current_stream()
+        b = self._buffers(slot, nq, depth, k, q.device)
+        side, pack = self.side[slot], b["pack"]
+        if self._used[slot] and not self._ended[slot]:
+            main.wait_event(b["fin"])
+        self.dense.search_begin(q, depth, slot, stream=main.cuda_stream)        # the HBM-heavy part: scans stay chained
+        b["scanned"].record(main)
+        side.wait_event(b["scanned"])
+        self._used[slot], self._ended[slot] = True, False
+        self.dense.search_finish(q, depth, slot, (pack[0, 0].view(torch.float64), b["s32"][0], pack[0, 1]),
+                                 stream=self._side_ptr[slot])
+        work = None
+        with torch.cuda.stream(side):
+            self.bm25.search_device(sparse_queries, depth, out=(pack[1, 0].view(torch.float64), b["s32"][1], pack[1, 1]))
+            if self.world > 1:
+                work = all_gather_packed(pack, b["gathered"], self.group, async_op=True)
+        return (work, slot, depth, k, c, w_dense, w_sparse)
+
+    def search_end(self, ticket, wait: bool = True):
+        """-> (fused scores float32 [nq,k], ids int64 [nq,k]), identical on every rank."""
+        import torch
+        from ._native import METRIC_IP
+        from .fusion import rrf_fuse_device
+        work, slot, depth, k, c, w_dense, w_sparse = ticket
+        b = self._bufs[slot]
+        side = self.side[slot]
+        with torch.cuda.stream(side):
+            if work is not None:
+                work.wait()
+            g = b["gathered"] if self.world > 1 else b["pack"].unsqueeze(0)
+            dl = merge_topk_device(g[:, 0, 0].view(torch.float64), g[:, 0, 1], depth, self.dense.metric, out=b["legs"][0])
+            sl = merge_topk_device(g[:, 1, 0].view(torch.float64), g[:, 1, 1], depth, METRIC_IP, out=b["legs"][1])
+            out = rrf_fuse_device(dl[2], sl[2], k, c, w_dense, w_sparse, out=b["fused"])
+            b["fin"].record(side)
+        self._ended[slot] = wait
+        if wait:
+            torch.cuda.current_stream().wait_event(b["fin"])
+        return out
 
     def search_device(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
                       w_sparse: float = 1.0):
-        """q: float32 CUDA tensor [nq, d] (the same on every rank); sparse_queries: nq term-id lists.  Every rank
-        returns the same fused (scores float32 [nq,k], ids int64 [nq,k])."""
+        """Any number of queries (the same on every rank); every rank returns the same fused (scores float32 [nq,k],
+        ids int64 [nq,k])."""
         import torch
         nq = q.shape[0]
-        pack = torch.empty((2, 2, nq, depth), dtype=torch.int64, device=q.device)
-        _pack_hybrid(self.dense, self.bm25, q, sparse_queries, depth, pack)
-        if self.world == 1:
-            gathered = pack.unsqueeze(0)
-        else:
-            gathered = torch.empty((self.world,) + tuple(pack.shape), dtype=torch.int64, device=q.device)
-            all_gather_packed(pack, gathered, self.group, async_op=False)
-        return _merge_and_fuse(gathered, depth, k, self.dense.metric, c, w_dense, w_sparse)
+        if nq <= self.max_pass:
+            return self.search_end(self.search_begin(q, sparse_queries, depth, k, c, w_dense, w_sparse))
+        out = (torch.empty((nq, k), dtype=torch.float32, device=q.device),
+               torch.empty((nq, k), dtype=torch.int64, device=q.device))
+        pending = []
+
+        def drain():
+            o, t = pending.pop(0)
+            for dst, src in zip(out, self.search_end(t)):
+                dst[o:o + src.shape[0]].copy_(src)
+
+        for o in range(0, nq, self.max_pass):
+            pending.append((o, self.search_begin(q[o:o + self.max_pass], sparse_queries[o:o + self.max_pass], depth, k, c,
+                                                 w_dense, w_sparse)))
+            if len(pending) >= N_SLOTS - 1:
+                drain()
+        while pending:
+            drain()
+        return out
 
 
 class EmulatedHybridShards:

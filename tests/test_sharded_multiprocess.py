@@ -159,3 +159,66 @@ def _gpu_worker(rank, world, port, q_out):
 @pytest.mark.gpu
 def test_sharded_index_two_ranks_on_one_gpu(gpu):
     _run(_gpu_worker, world=2, timeout=300)
+
+
+def _gpu_hybrid_worker(rank, world, port, q_out):
+    """ShardedHybrid (SURVEY 8e / configs[3] shape) with two ranks on one GPU over gloo: dense rows and postings split by
+    the same document ranges, pipelined batches (the launch size is forced down to 64 so that 150 queries run as three
+    pieces with several slots in flight), one packed all-gather per piece, fused lists == the unsharded oracle's."""
+    import torch
+    os.environ["HIPRAG_LAUNCH_QUERIES"] = "64"
+    dist = _setup(rank, world, port)
+    from hiprag import HipBM25, HipFlatIndex, PostingsCSR
+    from hiprag.sharded import ShardedHybrid, shard_bounds
+    from oracle import hybrid_oracle as ho
+    try:
+        torch.cuda.set_device(0)
+        n, d, depth, k, nq = 9001, 128, 50, 10, 150
+        x = ho.synthetic_vectors(n, d, seed=81)
+        q = ho.synthetic_queries(nq, d, seed=82)
+        p = ho.synthetic_postings(n, n_terms=512, seed=83)
+        sq = ho.synthetic_sparse_queries(nq, n_terms=512, terms_per_query=5, seed=84, min_rank=4)
+        lo, hi = shard_bounds(n, world)[rank]
+        local = HipFlatIndex(d, "ip")
+        local.add(x[lo:hi])
+        full = PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts)
+        sh = ShardedHybrid(local, HipBM25(full.shard(lo, hi)), lo)
+        assert sh.world == world and sh.max_pass == 64
+        qd = torch.from_numpy(q).cuda()
+        _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
+        _, bi = ho.bm25_search(p, sq, depth)
+        for (c, wd, ws) in [(60.0, 1.0, 1.0), (60.0, 0.7, 0.3)]:
+            fs, fi = sh.search_device(qd, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
+            torch.cuda.synchronize()
+            es, ei = ho.rrf_fuse(di, bi, k, c=c, w_a=wd, w_b=ws)
+            assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es)
+        q_out.put((rank, "ok"))
+    except Exception as e:
+        q_out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_hybrid_two_ranks_on_one_gpu(gpu):
+    _run(_gpu_hybrid_worker, world=2, timeout=300)
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_two_ranks_under_torch_distributed_run(gpu):
+    """bench.py --gpus 2 exactly as the driver launches it (python -m torch.distributed.run, one process per rank), except
+    that both ranks share cuda:0 over gloo (RCCL refuses two ranks on one device): argument, seed, shard and JSON paths of
+    the multi-GPU run are exercised on the one-GPU box."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--rows", "128000", "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["world"] == 2 and d["config"]["rows_local"] == [64000, 64000]
+    assert d["config"]["backend"] == "gloo" and d["config"]["allgather_payload_bytes_per_rank"] > 0
+    assert d["value"] > 0 and d["fallback_queries"] == 0 and "legs" not in d and "cpu_baseline" not in d
