@@ -158,3 +158,31 @@ def test_provider_and_reranker_refuse_to_serve_without_model_files(monkeypatch):
     with pytest.raises(RerankerError, match="HIP_RERANKER_WEIGHTS"):
         CrossEncoderReranker()
     f.set_embedding_provider(None)
+
+
+def test_file_tokenizer_on_an_xlmr_style_unigram_fixture():
+    """SURVEY 8f4 / VERDICT r1 item 7: the product's FileTokenizer on a committed SentencePiece-unigram tokenizer.json built
+    like XLM-RoBERTa's (NFKC + whitespace normaliser, Metaspace pre-tokeniser, fairseq id layout <s>=0 <pad>=1 </s>=2
+    <unk>=3, pieces from id 4, <mask> last).  Expected ids come from the `tokenizers` library in the build container
+    (tests/golden/make_unigram_fixture.py): our manual <s> ... </s> framing must equal the file's own XLM-R template, for
+    single texts and for <s> a </s></s> b </s> pairs, and truncation must keep the frame."""
+    from rag.providers.hip.tokenizer import FileTokenizer
+    gold = os.path.join(HERE, "golden")
+    exp = json.load(open(os.path.join(gold, "xlmr_style_unigram_expected.json"), encoding="utf-8"))
+    tk = FileTokenizer(os.path.join(gold, "xlmr_style_unigram_tokenizer.json"))
+    assert not tk.synthetic
+    for e in exp["single"]:
+        assert tk.encode(e["text"], 512) == e["ids_template"] == [0] + e["ids_no_special"] + [2], e["text"]
+        cut = tk.encode(e["text"], 6)
+        assert cut == ([0] + e["ids_no_special"][:4] + [2]) and len(cut) <= 6
+    for e in exp["pairs"]:
+        assert tk.encode_pair(e["a"], e["b"], 512) == e["ids_template"], (e["a"], e["b"])
+        short = tk.encode_pair(e["a"], e["b"], 12)
+        assert len(short) <= 12 and short[0] == 0 and short[-1] == 2 and short.count(2) == 3
+    by_text = {e["text"]: e for e in exp["single"]}
+    # the normaliser folds compatibility forms and whitespace runs: same ids as the plain spelling
+    assert by_text["  the   payment\tterms\n of the contract  "]["ids_no_special"] == tk.encode("the payment terms of the contract", 64)[1:-1]
+    assert 3 in by_text["xyzzy qwertyuiop 🙂"]["ids_no_special"]            # unknown pieces -> <unk> = 3, never a crash
+    assert by_text[""]["ids_template"] == [0, 2]                            # the empty string IS encoded (hf/embeddings.py:70-77)
+    assert all(i >= 4 for e in exp["single"] for i in e["ids_no_special"] if i != 3)      # pieces start after the 4 specials
+    assert exp["mask_id"] == exp["vocab_size"] - 1
