@@ -63,17 +63,26 @@ struct GemmArgs {
     int ksplit;
 };
 
-// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): far below the bf16 resolution of the value it feeds, and a third of
-// the instructions of the library erff in the FFN epilogue (the H->F GEMM is the largest single kernel of the encoder).
-__device__ __forceinline__ float erf_as(float x)
+// Exact-erf GELU, x * Phi(x), with ONE transcendental per element.  Phi(-z) = erfc(z / sqrt 2) / 2 for z = |x| is written
+// as exp2(p(z)), p = degree-7 polynomial fit of log2 Phi(-z) on [0, 6] (Chebyshev least squares in fp64, monomial
+// coefficients below): relative error of Phi(-z) <= 9.1e-6, absolute error of the GELU value <= 5.1e-7 over all x
+// (checked against fp64 erf on 2M points; bf16, which the value is rounded to next, resolves 3.9e-3 relative).  Then
+// GELU(x) = x * (x > 0 ? 1 - Phi(-z) : Phi(-z)); beyond |x| = 6 the tail is clamped at Phi(-6) = 1e-9.
+// The Abramowitz-Stegun form used before took two transcendentals (v_rcp, v_exp: 8 issue cycles each) and ~15 other
+// instructions per element; the H -> F epilogue runs 128 of these per lane and tile with nothing to hide behind.
+__device__ __forceinline__ float gelu_exact(float x)
 {
-    const float ax = fabsf(x);
-    // v_rcp_f32 (1 ulp) instead of a correctly rounded division: the IEEE sequence is ten instructions per element in
-    // the epilogue of the encoder's largest GEMM, and the approximation error of the formula itself is 1.5e-7
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float y = 1.f - poly * __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
-    return copysignf(y, x);
+    const float z = fminf(fabsf(x), 6.f);
+    float p = -1.9448814327915898e-06f;
+    p = __builtin_fmaf(p, z, 6.385969027178362e-05f);
+    p = __builtin_fmaf(p, z, -0.0009488638024777174f);
+    p = __builtin_fmaf(p, z, 0.008582341484725475f);
+    p = __builtin_fmaf(p, z, -0.05411824584007263f);
+    p = __builtin_fmaf(p, z, -0.4582975208759308f);
+    p = __builtin_fmaf(p, z, -1.1513246297836304f);
+    p = __builtin_fmaf(p, z, -0.9999869465827942f);
+    const float t = __builtin_amdgcn_exp2f(p);
+    return x * (x > 0.f ? 1.f - t : t);
 }
 
 // LDS tile image: 128 rows x 64 bf16 = 128-B rows of eight 16-B chunks, chunk kc of row r stored at slot kc ^ (r & 7).
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g)
         } else if (EPI == EPI_GELU) {
             bf16x8 o;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = (bf16)(0.5f * x[t] * (1.f + erf_as(x[t] * 0.70710678118654752f)));
+            for (int t = 0; t < 8; ++t) o[t] = (bf16)gelu_exact(x[t]);
             *reinterpret_cast<bf16x8*>(g.out_bf16 + (size_t)m * g.N + n) = o;
         } else {
             const bf16x8 rs = *reinterpret_cast<const bf16x8*>(g.resid + (size_t)m * g.N + n);
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g, int kc, in
                         *reinterpret_cast<bf16x4*>(dst) = o;
                     } else {  // EPI_GELU
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) o[u] = (bf16)(0.5f * x[u] * (1.f + erf_as(x[u] * 0.70710678118654752f)));
+                        for (int u = 0; u < 4; ++u) o[u] = (bf16)gelu_exact(x[u]);
                         *reinterpret_cast<bf16x4*>(g.out_bf16 + (size_t)m * g.N + n) = o;
                     }
                 }
@@ -466,51 +475,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// LayerNorm over bf16 pre-LN rows (the big-batch path: gemm256's RESID16 epilogue) -> bf16; one wave per row, the row is
-// read once (16 B per lane per load, H <= 2048 -> <= 4 loads), statistics in fp32.
+// LayerNorm over bf16 pre-LN rows (the big-batch path: gemm256's RESID16 epilogue) -> bf16.  One wave per FOUR consecutive
+// rows: all of their loads (16 B per lane each, H <= 1024 here: 2 per row) are in flight before the first reduction, gamma
+// and beta are loaded once per wave; statistics in fp32.  HBM-bound: 2 + 2 bytes per element.
+constexpr int kLn16Rows = 4;
 __global__ __launch_bounds__(256) void layernorm16_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, bf16* __restrict__ y, int M, int H,
                                                          float eps)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (size_t)row * H);
-    const int nvec = H >> 3;
-    bf16x8 v[4];
-    float s = 0.f;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kLn16Rows;
+    if (row0 >= M) return;
+    const int nvec = H >> 3;                                   // 16-B vectors per row, <= 128
+    const int c0 = min(lane, nvec - 1), c1 = min(64 + lane, nvec - 1);
+    const bool a0 = lane < nvec, a1 = 64 + lane < nvec;
+    bf16x8 v[kLn16Rows][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = i * 64 + lane;
-        v[i] = xr[min(c, nvec - 1)];
-        if (c < nvec) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
-        }
+    for (int r = 0; r < kLn16Rows; ++r) {
+        const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (size_t)min(row0 + r, M - 1) * H);
+        v[r][0] = xr[c0];
+        v[r][1] = xr[c1];
     }
-    const float mean = wave_sum(s) / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i * 64 + lane < nvec) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float a = (float)v[i][e] - mean; q += a * a; }
-        }
-    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-    bf16x8* yr = reinterpret_cast<bf16x8*>(y + (size_t)row * H);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float gg[2][8], bb[2][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = i * 64 + lane;
-        if (c < nvec) {
-            const float4 g0 = g4[2 * c], g1 = g4[2 * c + 1], b0 = b4[2 * c], b1 = b4[2 * c + 1];
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            bf16x8 o;
+    for (int i = 0; i < 2; ++i) {
+        const int c = i == 0 ? c0 : c1;
+        const float4 g0 = g4[2 * c], g1 = g4[2 * c + 1], b0 = b4[2 * c], b1 = b4[2 * c + 1];
+        gg[i][0] = g0.x; gg[i][1] = g0.y; gg[i][2] = g0.z; gg[i][3] = g0.w; gg[i][4] = g1.x; gg[i][5] = g1.y; gg[i][6] = g1.z; gg[i][7] = g1.w;
+        bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)v[i][e] - mean) * rstd * gg[e] + bb[e]);
-            yr[c] = o;
+    for (int r = 0; r < kLn16Rows; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (a0 ? (float)v[r][0][e] : 0.f) + (a1 ? (float)v[r][1][e] : 0.f);
+        const float mean = wave_sum(s) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d0 = (float)v[r][0][e] - mean, d1 = (float)v[r][1][e] - mean;
+            q += (a0 ? d0 * d0 : 0.f) + (a1 ? d1 * d1 : 0.f);
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+        if (row0 + r < M) {
+            bf16x8* yr = reinterpret_cast<bf16x8*>(y + (size_t)(row0 + r) * H);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)v[r][i][e] - mean) * rstd * gg[i][e] + bb[i][e]);
+                if (i == 0 ? a0 : a1) yr[i == 0 ? c0 : c1] = o;
+            }
         }
     }
 }
@@ -968,7 +985,7 @@ struct Encoder {
         const int T = nseq * S;
         // big batches: 256 x 256 persistent tiles (gemm256.h) once the narrowest GEMM (N = H) fills every CU
         const int M256 = ((T + G2_T - 1) / G2_T) * G2_T;
-        const bool big = big_ok(M256, H, H) && big_ok(M256, F, H) && big_ok(M256, H, F) && (M256 / G2_T) * (H / G2_T) >= n_cu;
+        const bool big = H <= 1024 && big_ok(M256, H, H) && big_ok(M256, F, H) && big_ok(M256, H, F) && (M256 / G2_T) * (H / G2_T) >= n_cu;
         const int M = big ? M256 : ((T + BM - 1) / BM) * BM;
         int32_t rc;
         if ((rc = tokens.reserve((size_t)nseq * S * 4))) return rc;
@@ -1041,7 +1058,7 @@ struct Encoder {
             } else if (big) {
                 o.out_bf16 = pre.as<bf16>();      // bf16 pre-LayerNorm rows: half the store and LayerNorm-read bytes
                 launch256<EPI_RESID16>(o, M, st);
-                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
+                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 4 * kLn16Rows - 1) / (4 * kLn16Rows)), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
                                    (const float*)L.ln1_g, (const float*)L.ln1_b, x.as<bf16>(), M, H, cfg.ln_eps);
             } else if (osplit > 1) {
                 o.ksplit = osplit;
@@ -1073,7 +1090,7 @@ struct Encoder {
             } else if (big) {
                 f2.out_bf16 = pre.as<bf16>();
                 launch256<EPI_RESID16>(f2, M, st);
-                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
+                hipLaunchKernelGGL(layernorm16_kernel, dim3((M + 4 * kLn16Rows - 1) / (4 * kLn16Rows)), dim3(256), 0, st, (const bf16*)pre.as<bf16>(),
                                    (const float*)L.ln2_g, (const float*)L.ln2_b, x.as<bf16>(), M, H, cfg.ln_eps);
             } else if (dsplit > 1) {
                 f2.ksplit = dsplit;

@@ -213,8 +213,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
                 G2_KTILE(1);
             }
         }
-        if (wr == 0) G2_BAR();   // group 1 finishes its last compute half-step: both groups are level again
-
         // ---- epilogue: wave-private transposition through 4 KiB of LDS, 16-byte global vectors ------------------------------
         int m0, n0;
         tile_origin(L, m0, n0);
@@ -227,7 +225,21 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         asm volatile("" : "+v"(lane_e));
         const int r16 = lane_e & 15, kq = lane_e >> 4;
         const int rrow = lane_e >> 4, rc = lane_e & 15;   // read-back: row 4t + rrow, 16-B chunk rc
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        // bias of the bf16 epilogues: inline-asm loads (hand-counted, see the residual epilogue) issued BEFORE the levelling
+        // barrier, so that for group 0 their round trip overlaps group 1's last compute half-step
+        u32x4 bq8[8];
+        if (EPI == EPI_GELU) {       // (the QKV epilogue has two forms and no registers to spare: its bias loads stay hipcc's)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float* bp = g.bias + n0 + wr * 128 + i * 16 + 4 * kq;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq8[i]) : "v"(bp) : "memory");
+            }
+        }
+        if (wr == 0) G2_BAR();   // group 1 finishes its last compute half-step: both groups are level again
+
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        (void)bq8; (void)rrow; (void)rc;
         if (EPI == EPI_RESID || EPI == EPI_RESID16) {
             // normal orientation: acc[i][j][r] = C[m0 + wc*64 + j*16 + r16][n0 + wr*128 + i*16 + 4kq + r].
             // Chunk (j, h2) = 16 rows x 64 columns of fp32 through the wave's scratch; read back as 8 consecutive columns per
@@ -237,7 +249,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
             // All global loads are inline asm with hand-counted waits: beside the LDS-DMA stream hipcc answers every ordinary
             // load with `vmcnt(0)`, which here also waits for every store issued so far -- one memory round trip per chunk.
             // Rows are never masked: M is a whole number of tiles for these two epilogues (launch condition).
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             const int mb = m0 + wc * 64, nb = n0 + wr * 128;
             const int rb_row = lane_e >> 3, c8 = lane_e & 7;
             u32x4 bq[2][2];                 // bias[nb + h2*64 + c8*8 + 0..7] as two float4
@@ -336,21 +347,28 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         } else {
             // row-major bf16 outputs (GELU; q and k of QKV), normal orientation
             const int mb = m0 + wc * 64, nb = n0 + wr * 128;
-            float4 bias4[8];
+            if (EPI == EPI_GELU) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq8[0]), "+v"(bq8[1]), "+v"(bq8[2]), "+v"(bq8[3]), "+v"(bq8[4]), "+v"(bq8[5]),
+                             "+v"(bq8[6]), "+v"(bq8[7]) :: "memory");
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bias4[i] = *reinterpret_cast<const float4*>(g.bias + nb + i * 16 + 4 * kq);
+                for (int i = 0; i < 8; ++i) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + nb + i * 16 + 4 * kq);
+                    bq8[i] = u32x4{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)};
+                }
+            }
             const int which = EPI == EPI_QKV ? n0 / g.H : 0;      // 0 = q (scaled by 1/8, exact), 1 = k
             const float scale = (EPI == EPI_QKV && which == 0) ? 0.125f : 1.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float x[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z,
-                                  acc[i][j][3] + bias4[i].w};
+                    float x[4] = {acc[i][j][0] + __uint_as_float(bq8[i][0]), acc[i][j][1] + __uint_as_float(bq8[i][1]),
+                                  acc[i][j][2] + __uint_as_float(bq8[i][2]), acc[i][j][3] + __uint_as_float(bq8[i][3])};
                     bf16x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] = EPI == EPI_GELU ? (bf16)(0.5f * x[r] * (1.f + erf_as(x[r] * 0.70710678118654752f)))
+                        v[r] = EPI == EPI_GELU ? (bf16)gelu_exact(x[r])
                                                : (bf16)(x[r] * scale);
                     *reinterpret_cast<bf16x4*>(sc + r16 * 256 + (((i * 2 + (kq >> 1)) ^ r16) << 4) + (kq & 1) * 8) = v;
                 }
