@@ -90,7 +90,7 @@ def main():
 
     t_dense, (d64, d32, dids) = timeit(run_dense)
     b0 = bm25.stats()
-    t_sparse, (s64, s32, sids) = timeit(run_sparse, reps=1)
+    t_sparse, (s64, s32, sids) = timeit(run_sparse, reps=5)
     b1 = bm25.stats()
     t_fuse, (fs, fids) = timeit(lambda: rrf_fuse_device(dids, sids, k))
 
@@ -134,8 +134,11 @@ def main():
         "nq": args.nq, "postings": int(postings.offsets[-1]), "postings_build_s": round(build_s, 1),
         "dense_qps": round(args.nq / t_dense, 1), "bm25_qps": round(args.nq / t_sparse, 1),
         "rrf_qps": round(args.nq / t_fuse, 1), "hybrid_qps": round(args.nq / t_all, 1),
-        "bm25_algorithmic_GBs": round(bytes_sparse / t_sparse / 1e9, 1),
-        "bm25_postings_per_query": int((b1["postings_touched"] - b0["postings_touched"]) / args.nq),
+        # the stats window spans 1 warm-up + 5 timed calls (round 1 divided by one call only and so quoted these two
+        # figures twice too high: 899,608 postings per query, 7.2 TB/s)
+        "bm25_survey8d_accounting_GBs": round(bytes_sparse / 6 / t_sparse / 1e9, 1),
+        "bm25_postings_per_query": int((b1["postings_touched"] - b0["postings_touched"]) / 6 / args.nq),
+        "bm25_posting_bytes_requested_GBs": round((b1["postings_touched"] - b0["postings_touched"]) / 6 * 8 / t_sparse / 1e9, 1),
         "oracle_check": ok}))
 
 
