@@ -440,14 +440,14 @@ def main():
                                               "ids_equal_gpu_fraction": round(float(np.mean(be_ids == gbi)), 4)}
     # HBM traffic of the scan kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside this
     # process); the committed summary applies to the full-size single-GPU workload only.
-    pmc = os.path.join(REPO, "profiles", "r01_pmc_scan.json")
+    pmc = os.path.join(REPO, "profiles", "r02_pmc_scan.json")
     if world == 1 and n_rows == N_ROWS and os.path.exists(pmc):
         with open(pmc) as f:
             p = json.load(f)
         # NOT measured in this run: counters cannot be read from inside the process.  `traffic` stays null; the number of the
         # committed PMC summary (same binary path, same workload) travels under a key that says where it comes from.
         out["roofline"]["traffic_from_profile"] = {"bytes_per_launch": int(p["traffic_bytes_per_launch"]),
-                                                   "source": "profiles/r01_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                   "source": "profiles/r02_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                              "WRITE_SIZE, separate passes; not collected by this run)"}
     if world == 1 and args.legs != "none":
         del sharded
