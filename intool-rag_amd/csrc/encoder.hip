@@ -951,7 +951,7 @@ struct Encoder {
     {
         const int nbm = Mpad / G2_T, nbn = a.N / G2_T;
         const int grid = std::min(nbm * nbn, n_cu);
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn, 0, 0);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn, 0);
     }
 
     // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
@@ -1235,12 +1235,10 @@ int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_de
     if (impl >= 2 || epilogue == 3 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
         const int nbm = M / G2_T, nbn = N / G2_T, grid = std::min(nbm * nbn, cus);
         const int dbg = impl >= 3 ? impl - 2 : 0;   // bit 0: no staging, bit 1: no MFMAs, bit 2: no fragment reads
-        const char* sk = std::getenv("HIPENC_GEMM_SKEW");
-        const int skew = sk ? std::atoi(sk) : 0;
-        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
-        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
-        else if (epilogue == 3) hipLaunchKernelGGL(gemm256_kernel<EPI_RESID16>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
-        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg, skew);
+        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
+        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
+        else if (epilogue == 3) hipLaunchKernelGGL(gemm256_kernel<EPI_RESID16>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
+        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
     } else {
         const dim3 grid((N / BN) * (M / BM));
         if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, grid, dim3(kGemmThreads), 0, st, g);

@@ -53,7 +53,7 @@ constexpr int G2_LDS_BYTES = 2 * G2_SLAB + 8 * 4096;
     } while (0)
 
 template <int EPI>
-__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn, int dbg = 0, int skew = 0)
+__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn, int dbg = 0)
 {
     __shared__ __attribute__((aligned(16))) char lds[G2_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -112,15 +112,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         }
     };
     if (!svalid) return;
-    // De-phase the workgroups: all of them start together and every tile takes the same time, so without this all 256 CUs
-    // reach their epilogues -- the only HBM-heavy part of the kernel -- at the same moment, and the store bursts queue up
-    // behind one another while HBM idles during the main loops.  A pseudo-random start delay of up to `skew` x 64 clocks
-    // (about one tile) spreads them out.
-    if (skew > 0) {
-        const unsigned ph = ((unsigned)vw * 2654435761u) >> 20;           // 12 bits
-        const int n = (int)(((unsigned long long)ph * (unsigned)skew) >> 12) / 127;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     cursor_tile();
     // prologue: k-tile 0 whole (the state every later tile boundary is in as well: the cursor k-tile has landed)
     issue_half(sP, 0, lds + 0 * 16384);

@@ -107,3 +107,84 @@ def test_bad_inputs_raise(gpu):
         enc.encode_tokens([[0] + [5] * 60 + [2]])        # longer than the position table
     with pytest.raises(ValueError):
         enc.score_tokens([[0, 5, 2]])                    # no classification head
+
+
+def _linear(epi, impl, a, w, bias, resid=None, S=64, heads=16):
+    import torch
+    from hiprag import _native as nat
+    from hiprag.index import _stream_ptr as sp
+    M, K = a.shape
+    N = w.shape[0]
+    dev = a.device
+    if epi == 0:
+        q = torch.zeros((M // S, heads, S, 64), dtype=torch.bfloat16, device=dev)
+        k = torch.zeros_like(q)
+        vt = torch.zeros((M // S, heads, 64, S), dtype=torch.bfloat16, device=dev)
+        nat.call("hipenc_linear", a.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, 0, None, q.data_ptr(), k.data_ptr(),
+                 vt.data_ptr(), S, heads, impl, sp())
+        return q, k, vt
+    out = torch.zeros((M, N), dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
+    nat.call("hipenc_linear", a.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, epi,
+             resid.data_ptr() if resid is not None else None, out.data_ptr(), None, None, 0, 0, impl, sp())
+    return (out,)
+
+
+@pytest.mark.parametrize("epi,N,K", [(0, 3072, 1024), (1, 4096, 1024), (2, 1024, 4096), (3, 1024, 1024)])
+def test_linear_layers_both_tiled_kernels_against_fp32_reference(gpu, epi, N, K):
+    """hipenc_linear: the 128 x 128 kernel and the persistent 256 x 256 ping-pong kernel (csrc/gemm256.h) on the encoder's
+    four layer shapes with their fused epilogues -- QKV scatter (q scaled, head-major q / k, TRANSPOSED v through the
+    swapped-role tiles), exact GELU, bias + residual in fp32 and in bf16 -- against an fp32 torch reference on the same bf16
+    operands, and against each other BIT FOR BIT (same ascending-k fp32 accumulation).  1536 rows = 6 row tiles: more tiles
+    than one pass of a small grid, partial XCD super-rows."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7 + epi)
+    M, S, heads = 1536, 64, 16
+    a = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.03).to(torch.bfloat16)
+    bias = torch.randn((N,), generator=g, device=dev) * 0.1
+    resid = torch.randn((M, N), generator=g, device=dev).to(torch.bfloat16) if epi >= 2 else None
+    c = a.float() @ w.float().T + bias
+    if epi == 0:
+        H = N // 3
+        nseq = M // S
+        ref = ((c[:, :H] * 0.125).view(nseq, S, heads, 64).permute(0, 2, 1, 3), c[:, H:2 * H].view(nseq, S, heads, 64).permute(0, 2, 1, 3),
+               c[:, 2 * H:].view(nseq, S, heads, 64).permute(0, 2, 3, 1))
+    elif epi == 1:
+        ref = (torch.nn.functional.gelu(c),)
+    else:
+        ref = (c + resid.float(),)
+    outs = {}
+    for impl in ((2,) if epi == 3 else (1, 2)):
+        out = _linear(epi, impl, a, w, bias, resid, S, heads)
+        torch.cuda.synchronize()
+        outs[impl] = out
+        for o, r in zip(out, ref):
+            tol = 5e-4 if epi == 2 else 2.0 ** -8          # fp32 output: accumulation-order noise over K <= 4096; bf16 outputs: one rounding
+            err = ((o.float() - r).abs() / (r.abs() + 0.05)).max().item()
+            assert err <= tol, (epi, impl, err)
+    if len(outs) == 2:
+        assert all(torch.equal(x, y) for x, y in zip(outs[1], outs[2]))
+
+
+def test_big_batch_path_with_padded_row_tiles_and_masks(gpu, monkeypatch):
+    """261 x 64-token rows = 16704 token rows: enough for the persistent 256-tile GEMMs (>= 16 k rows), and NOT a multiple of
+    256, so the last row tile is padding -- the QKV epilogue has to mask its scatter, the pad rows must never reach a real
+    token.  Checked against the fp32 oracle on a sample of sequences (incl. the last ones) and against the 128-tile path."""
+    from hiprag import EncoderConfig, HipEncoder, random_state
+    cfg = EncoderConfig(vocab=3000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=100, max_seq_len=64)
+    sd = random_state(cfg, seed=13)
+    rng = np.random.default_rng(13)
+    lens = [64] * 200 + rng.integers(3, 65, size=61).tolist()
+    toks = _tokens(rng, lens, cfg.vocab)
+    big = HipEncoder(cfg, sd).encode_tokens(toks, batch_size=512).cpu().numpy()
+    pick = [0, 1, 199, 200, 230, 259, 260]
+    ref = eo.embed_fp32(eo.bf16_round_state(sd), [toks[i] for i in pick], cfg.layers, cfg.heads, cfg.pad_id, cfg.ln_eps)
+    cos = np.sum(big[pick] * ref, axis=1)
+    print(f"\n[big-batch path, 16704 rows] min cosine {cos.min():.6f}  max |delta| {np.abs(big[pick] - ref).max():.3e}")
+    assert cos.min() >= MIN_COS and np.abs(big[pick] - ref).max() <= MAX_ABS_SQRT_H / np.sqrt(cfg.hidden)
+    monkeypatch.setenv("HIPENC_GEMM256", "0")
+    small_tiles = HipEncoder(cfg, sd).encode_tokens(toks, batch_size=512).cpu().numpy()
+    assert np.allclose(big, small_tiles, atol=3e-3)       # bf16 pre-LN rows vs fp32 ones: rounding noise only
+    assert np.all(np.isfinite(big)) and np.allclose(np.linalg.norm(big, axis=1), 1.0, atol=1e-3)
