@@ -277,7 +277,7 @@ def main():
     # bf16 copy of the local rows once for its own query tile).  The library sizes a launch by the LOCAL row count so that
     # it lasts about as long whatever the shard: 8 passes at 1M rows, 16 (1024 queries) at <= 500k rows per GPU.
     # HIPRAG_LAUNCH_QUERIES / HIPRAG_SCAN_MODE change the split
-    BATCH = index.launch_queries
+    BATCH = sharded.max_pass          # = index.launch_queries on one GPU; the MINIMUM over the ranks otherwise (agreed at construction)
     PASSES = (BATCH + index.pass_queries - 1) // index.pass_queries
     nb = N_QUERIES // BATCH
 
