@@ -951,7 +951,7 @@ struct Encoder {
     {
         const int nbm = Mpad / G2_T, nbn = a.N / G2_T;
         const int grid = std::min(nbm * nbn, n_cu);
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn, 0);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(G2_THREADS), 0, st, a, nbm, nbn);
     }
 
     // K range per workgroup of the small-batch GEMM: K / ksplit, a multiple of 128 and at most 1024
@@ -1212,7 +1212,7 @@ int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_de
     HR_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0, "M, N multiples of 128 and K of 64");
     HR_REQUIRE(epilogue >= 0 && epilogue <= 3, "epilogue: 0 = qkv, 1 = gelu, 2 = bias + residual -> f32, 3 = bias + residual -> bf16");
     HR_REQUIRE(epilogue != 3 || impl != 1, "the bf16 residual epilogue exists in the 256-tile kernel only");
-    HR_REQUIRE(impl >= 0 && impl <= 9, "impl: 0 = auto, 1 = 128 x 128 tiles, 2 = 256 x 256 persistent tiles (3 / 4: timing experiments)");
+    HR_REQUIRE(impl >= 0 && impl <= 2, "impl: 0 = auto, 1 = 128 x 128 tiles, 2 = 256 x 256 persistent tiles");
     GemmArgs g{};
     g.A = (const bf16*)a_dev; g.W = (const bf16*)w_dev; g.bias = bias_dev; g.M = M; g.N = N; g.K = K;
     if (epilogue == EPI_QKV) {
@@ -1229,16 +1229,15 @@ int32_t hipenc_linear(const void* a_dev, const void* w_dev, const float* bias_de
     HR_CHECK_HIP(hipGetDevice(&dev));
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool can256 = M % G2_T == 0 && N % G2_T == 0 && K % (2 * G2_BK) == 0 && (epilogue != EPI_QKV || g.H % G2_T == 0);
-    HR_REQUIRE(impl < 2 || can256, "the 256-tile kernel needs M, N multiples of 256 and K of 128");
+    HR_REQUIRE(impl != 2 || can256, "the 256-tile kernel needs M, N multiples of 256 and K of 128");
     hipStream_t st = (hipStream_t)stream;
     HR_REQUIRE(epilogue != 3 || can256, "the bf16 residual epilogue needs M, N multiples of 256 and K of 128");
-    if (impl >= 2 || epilogue == 3 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
+    if (impl == 2 || epilogue == 3 || (impl == 0 && can256 && (M / G2_T) * (N / G2_T) >= cus)) {
         const int nbm = M / G2_T, nbn = N / G2_T, grid = std::min(nbm * nbn, cus);
-        const int dbg = impl >= 3 ? impl - 2 : 0;   // bit 0: no staging, bit 1: no MFMAs, bit 2: no fragment reads
-        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
-        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
-        else if (epilogue == 3) hipLaunchKernelGGL(gemm256_kernel<EPI_RESID16>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
-        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn, dbg);
+        if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        else if (epilogue == EPI_GELU) hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        else if (epilogue == 3) hipLaunchKernelGGL(gemm256_kernel<EPI_RESID16>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
+        else hipLaunchKernelGGL(gemm256_kernel<EPI_RESID>, dim3(grid), dim3(G2_THREADS), 0, st, g, nbm, nbn);
     } else {
         const dim3 grid((N / BN) * (M / BM));
         if (epilogue == EPI_QKV) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, grid, dim3(kGemmThreads), 0, st, g);

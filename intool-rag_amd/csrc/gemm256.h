@@ -53,7 +53,7 @@ constexpr int G2_LDS_BYTES = 2 * G2_SLAB + 8 * 4096;
     } while (0)
 
 template <int EPI>
-__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn, int dbg = 0)
+__global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm, int nbn)
 {
     __shared__ __attribute__((aligned(16))) char lds[G2_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         }
     };
     auto issue_half = [&](const bf16* rowbase, int half, char* dst) {   // 16 KiB = 16 wave-instructions, 2 per wave
-        if (dbg & 1) return;   // timing experiments only (hipenc_linear impl 3): no staging, the MFMAs run on whatever LDS holds
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int inst = wave * 2 + u;
@@ -153,14 +152,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
         if (wr == 1) G2_BAR();   // stagger: group 1 runs half a phase behind group 0
 
 #define G2_LDA(B, sub)                                                                          \
-    if (!(dbg & 4)) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
         a[i][ks] = *reinterpret_cast<const bf16x8*>(pA[B][ks] + ((sub) * 4 + i) * 2048)
 #define G2_LDB(B)                                                                               \
-    if (!(dbg & 4)) _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
         b[j][ks] = *reinterpret_cast<const bf16x8*>(pB[B][ks] + j * 2048)
 #define G2_MFMA(as)                                                                             \
     do {                                                                                        \
-        if (dbg & 2) break;   /* timing experiments only: staging and barriers without the MFMAs */ \
         __builtin_amdgcn_s_setprio(1);                                                          \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
