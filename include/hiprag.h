@@ -141,6 +141,15 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
  * 0 = off.  Two event records cost ~20 us of dispatch bubble between chained launches, hence the sampling.  get_stats syncs. */
 int32_t hipidx_enable_timing(uint64_t h, int32_t on);
 
+/* Exact top-k (k <= 64) of each of n_rows float arrays of n values (row r at vals + r * row_stride; 16-byte aligned, stride
+ * a multiple of 4) under the library's canonical order: larger value first, then LOWER index; -inf entries are "absent".
+ * out_vals / out_idx [n_rows, k], exhausted ranks -inf / -1.  This is the selector the dense finish runs over a query's
+ * group maxima (one 1024-thread workgroup per array, one threshold pass: csrc/topk_device.h select_threshold_topk),
+ * exported so that its edge cases can be tested directly.  The reference has no counterpart (FAISS's heap inside
+ * IndexFlat::search, rag/storage/faiss_index.py:137). */
+int32_t hiprag_select_topk_dev(const float* vals_dev, int64_t row_stride, int64_t n, int32_t n_rows, int32_t k,
+                               float* out_vals_dev, int64_t* out_idx_dev, void* stream);
+
 /* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
  * in_scores64 / in_ids: n_parts blocks of [nq, k_in] (device), block p starting part_stride ELEMENTS after block
  * p-1 (0 = dense, nq*k_in) so both arrays can live interleaved in one all-gathered buffer.  Canonical comparator

@@ -292,9 +292,8 @@ __device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 
 }
 
 // Park one block's lane maximum in a 16-register shift chain (mh[0] = newest); on the last block of a chunk (or of the
-// wave's range) write the chunk out as one run per lane.  Registers, not LDS: the query tile already takes 128 KiB and
-// the remaining 32 KiB must stay free so that the tail kernels of earlier passes can be co-resident with a scan
-// workgroup.  Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
+// wave's range) write the chunk out as one run per lane.  Registers, not LDS: the query tile already takes 128 KiB.
+// Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
 // make it drain the queue; in the hand-counted vmcnt they are extra YOUNGER ops.
 template <int kChunk>
 __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int64_t blk, int64_t b0, int64_t b1, int lane,
@@ -319,6 +318,52 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
         for (int t = 0; t < kChunk; ++t)
             if (t < cnt) dst[cnt - 1 - t] = mh[t];
     }
+}
+
+// The bf16 scan's forms of the flush.  park() keeps the shift chain; flush_full() writes a complete chunk (kChunk / 4
+// 16-byte stores per lane, back to back), flush_partial() the short last chunk of a range.
+// What the output costs (1M x 1024, 512 queries per launch: 256 MB of group maxima beside 16.4 GB of rows; scan alone
+// 2.40 ms with the stores compiled out): 8-block chunks, i.e. a 64-byte half line per query and flush, +0.17 to +0.5 ms
+// depending on where the allocation landed; 16-block chunks = whole 128-byte lines (rows are line aligned: gmax_stride),
+// +0.03 to +0.3 ms.  Whole lines must reach L2 TOGETHER: the same 16-block chunk written four stores at a time over the
+// next twelve blocks (so that no burst of 16 stores sits in the wave's vmcnt) was 10 % slower than the burst, `nt`
+// stores 25 % slower, a [chunk][query] layout with 8 KiB contiguous per flush slower than the per-query rows, and
+// staging through LDS so that each store instruction writes eight whole lines changed nothing.
+// The stores are plain C++ stores: hipcc sees no other vector-memory operation in the loop, so they never make it drain
+// the queue, and it keeps the wait state a 16-byte store needs before its data registers are written again (an inline-asm
+// store followed by the next flush's register moves corrupted values).  In the ring's counted waits they are extra
+// operations in flight: vmcnt(RING - 1) then waits for more than it needs, never for less (loads return in order among
+// themselves; allowing for the stores with a larger count is NOT safe: acknowledgements of stores overtake older loads).
+template <int kChunk>
+__device__ __forceinline__ void park(float (&mh)[kChunk], float m)
+{
+#pragma unroll
+    for (int t = kChunk - 1; t > 0; --t) mh[t] = mh[t - 1];
+    mh[0] = m;
+}
+
+template <int kChunk>
+__device__ __forceinline__ void flush_full(const float (&mh)[kChunk], int lane, float* __restrict__ gm, int64_t gstride, int qoff,
+                                           int64_t cb)
+{
+    const int h = lane >> 5, qb = (lane & 31) + qoff;
+    float* dst = gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * kChunk;
+#pragma unroll
+    for (int v = 0; v < kChunk / 4; ++v) {   // block cb + t sits in mh[kChunk - 1 - t]
+        reinterpret_cast<float4*>(dst)[v] = make_float4(mh[kChunk - 1 - 4 * v], mh[kChunk - 2 - 4 * v], mh[kChunk - 3 - 4 * v],
+                                                        mh[kChunk - 4 - 4 * v]);
+    }
+}
+
+template <int kChunk>
+__device__ __forceinline__ void flush_partial(const float (&mh)[kChunk], int cnt, int lane, float* __restrict__ gm, int64_t gstride,
+                                              int qoff, int64_t cb)
+{
+    const int h = lane >> 5, qb = (lane & 31) + qoff;
+    float* dst = gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * cnt;
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t)
+        if (t < cnt) dst[cnt - 1 - t] = mh[t];
 }
 
 template <int METRIC, int NWAVES, int RING = 16>
@@ -651,12 +696,11 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
 // prologue, passes back to back with a cyclic piece stream, first / second quad values per group.
 // Query tile in LDS: piece p, lane (h, b): Q^[b][16p + 8h + 0..7] for queries 0..31, then the same for queries 32..63.
 // ------------------------------------------------------------------------------------------------------
-template <int METRIC, int NWAVES, int RING, bool MULTI>
+template <int METRIC, int NWAVES, int RING, bool MULTI, int CH = 8>
 __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
 {
     extern __shared__ float4 qs[];
     constexpr int NT = NWAVES * 64;
-    constexpr int CH = 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -678,7 +722,6 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
         for (int u = 0; u < 2; ++u) { mh[u][t] = 0.f; ms[u][t] = 0.f; }
     const unsigned lane16 = (unsigned)lane * 16u;
     const int h = lane >> 5;
-
     f32x4 ring[RING];
     if (S > 0) {
 #pragma unroll
@@ -697,7 +740,11 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
         {
             bf16x8* qw = reinterpret_cast<bf16x8*>(qs);
             const bool vec_ok = (a.d & 3) == 0;
-            int idx0 = tid;
+            // opaque copies of the thread / lane index at the top of every pass and block epilogue: left visible, hipcc hoists
+            // their address arithmetic out of the pass loop and keeps ~60 registers of it alive through the ring loop
+            int tid_p = tid;
+            asm volatile("" : "+v"(tid_p));
+            int idx0 = tid_p;
             if (vec_ok && a.d >= 4) {
                 // four fragments per step, their eight 16-B loads issued together and UNCONDITIONALLY (clamped query and
                 // column, masked afterwards): predicated, each load was a branch + load + s_waitcnt vmcnt(0) -- 32
@@ -779,7 +826,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
             for (int pp = 0; pp < P2; pp += RING) {
 #pragma unroll
                 for (int i = 0; i < RING; ++i) {
-                    // one step = one 1 KiB piece (16 k-values): two MFMAs (one per query tile), re-arm the ring slot
+                    // one step = one 1 KiB piece (16 k-values): two MFMAs (one per query tile), re-arm the ring slot.
+                    // vmcnt(RING - 1) is exact with only the ring in flight; stores in flight (and the L2 metric's norm
+                    // loads) make it wait for more than it needs, never for less -- loads return in order among themselves
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[i]) : "n"(RING - 1) : "memory");
                     const bf16x8 av = __builtin_bit_cast(bf16x8, ring[i]);
                     const bf16x8 bv0 = n0v, bv1 = n1v;
@@ -799,13 +848,25 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
             }
             if (METRIC == HIPRAG_METRIC_L2)
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
-            float sec;
-            float fst = block_lane_top2<METRIC>(acc0, nrm, blk, h, a, sec);
-            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
-            fst = block_lane_top2<METRIC>(acc1, nrm, blk, h, a, sec);
-            park_and_flush(mh[1], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase + 32);
-            park_and_flush(ms[1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase + 32);
+            float sec, sec1;
+            int lane_b = lane;
+            asm volatile("" : "+v"(lane_b));
+            const int h_b = lane_b >> 5;
+            const float fst = block_lane_top2<METRIC>(acc0, nrm, blk, h_b, a, sec);
+            const float fst1 = block_lane_top2<METRIC>(acc1, nrm, blk, h_b, a, sec1);
+            const int j = (int)((blk - b0) % CH);
+            park(mh[0], fst); park(ms[0], sec); park(mh[1], fst1); park(ms[1], sec1);
+            if (j == CH - 1) {
+                flush_full(mh[0], lane_b, a.gmax, a.gstride, qbase, blk - j);
+                flush_full(ms[0], lane_b, a.gmax2, a.gstride, qbase, blk - j);
+                flush_full(mh[1], lane_b, a.gmax, a.gstride, qbase + 32, blk - j);
+                flush_full(ms[1], lane_b, a.gmax2, a.gstride, qbase + 32, blk - j);
+            } else if (blk == b1 - 1) {   // the short last chunk of the range
+                flush_partial(mh[0], j + 1, lane_b, a.gmax, a.gstride, qbase, blk - j);
+                flush_partial(ms[0], j + 1, lane_b, a.gmax2, a.gstride, qbase, blk - j);
+                flush_partial(mh[1], j + 1, lane_b, a.gmax, a.gstride, qbase + 32, blk - j);
+                flush_partial(ms[1], j + 1, lane_b, a.gmax2, a.gstride, qbase + 32, blk - j);
+            }
         }
     }  // pass
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1105,6 +1166,35 @@ __global__ __launch_bounds__(NW * 64) void fin_merge_kernel(FinishArgs a)
             a.qn2[2 * q] = qn2;
             a.qn2[2 * q + 1] = dq2;
         }
+    }
+}
+
+// fin_select_kernel: select_wave_kernel + fin_merge_kernel in one launch, one 16-wave workgroup per query: the K' + 1 best
+// group maxima by one threshold pass over the query's `first` array (select_threshold_topk, topk_device.h) -> sel[q][0..K'],
+// and the query's exact |q|^2 and |q - bf16(q)|^2.
+__global__ __launch_bounds__(1024) void fin_select_kernel(FinishArgs a, const float* __restrict__ gmax, i64 gstride, i64 ngroups)
+{
+    __shared__ SelectScratch S;
+    __shared__ double dred[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;
+    double qpart = 0.0, dpart = 0.0;
+    for (int c = tid; c < a.d; c += 1024) {
+        const float vf = a.q[(int64_t)q * a.d + c];
+        const double v = (double)vf, dv = v - (double)(float)(__bf16)vf;   // the scan's query tile holds bf16(q), RNE
+        qpart += v * v;
+        dpart += dv * dv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
+    if (lane == 0) { dred[wave] = qpart; dred[16 + wave] = dpart; }
+    select_threshold_topk(gmax + (i64)q * gstride, ngroups, a.Kp + 1, S, a.sel + (int64_t)q * 64);   // has barriers
+    if (tid == 0) {
+        double qn2 = 0.0, dq2 = 0.0;
+        for (int w = 0; w < 16; ++w) { qn2 += dred[w]; dq2 += dred[16 + w]; }
+        a.qn2[2 * q] = qn2;
+        a.qn2[2 * q + 1] = dq2;
     }
 }
 
@@ -1529,6 +1619,15 @@ __global__ __launch_bounds__(kSelThreads) void exhaustive_kernel(ExArgs a)
 // host object
 // ------------------------------------------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, size) instead of on every launch
+// Row stride of the group-maxima arrays, in floats: a multiple of 32 so that every query's row starts on a 128-byte line
+// and a wave's 16-block chunk (32 floats per query) is exactly one line (with rows at 16-byte granularity every flush
+// straddled two lines: partial-line writes all the way to HBM).  HIPRAG_GMAX_ALIGN overrides (experiments).
+static int64_t gmax_stride(int64_t nblocks)
+{
+    static const int64_t al = [] { const char* e = getenv("HIPRAG_GMAX_ALIGN"); return e ? std::max<int64_t>(4, atoll(e)) : (int64_t)32; }();
+    return ((2 * nblocks + al - 1) / al) * al;
+}
+
 static int32_t ensure_lds(const void* fn, size_t bytes)
 {
     static std::mutex mu;
@@ -1616,6 +1715,8 @@ struct DenseIndex {
         launch_env = lq ? atoi(lq) : 0;
         if (const char* sw = getenv("HIPRAG_SCAN_WAVES_SMALL")) scan_waves_small = atoi(sw);
         if (const char* sb = getenv("HIPRAG_SCAN_WAVES_SMALL_BLOCKS")) scan_waves_small_blocks = std::max(1, atoi(sb));
+        if (const char* sc = getenv("HIPRAG_SCAN_CHUNK")) scan_chunk = atoi(sc) == 8 ? 8 : 16;
+        if (const char* se = getenv("HIPRAG_SELECT")) select_by_threshold = se[0] != 'w';
         update_launch_q();
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
@@ -1711,6 +1812,8 @@ struct DenseIndex {
     // three 32-row blocks per pass; 4-wave workgroups stream twice as many each and leave half of every SIMD's registers to
     // the tail kernels of earlier steps.  Measured (1024 queries per launch, pipelined): 125 k rows 945 -> 902 us per step,
     // 250 k 1640 -> 1590, 500 k 2758 -> 2857 (slower), 1M equal -- so below 5 blocks per wave of the 8-wave partition.
+    bool select_by_threshold = true;   // HIPRAG_SELECT=wave: the per-wave selectors (select_wave_kernel) instead
+    int scan_chunk = 16;               // HIPRAG_SCAN_CHUNK: blocks per flush of the multi-pass bf16 scan (16 = whole 128-byte lines)
     int scan_waves_small = 1;          // HIPRAG_SCAN_WAVES_SMALL=0 keeps 8 waves everywhere
     int scan_waves_small_blocks = 5;   // HIPRAG_SCAN_WAVES_SMALL_BLOCKS
     int mode_for(int k) const { return (scan_mode >= 2 && k > kMaxK64) ? 1 : scan_mode; }
@@ -1740,7 +1843,7 @@ struct DenseIndex {
         if (k <= w.k && nb <= w.blocks && launch_q <= w.q) return HIPRAG_OK;
         const int kk = std::max(k, w.k);
         const int64_t nbb = std::max(nb, w.blocks);
-        const int64_t gstride = ((2 * nbb + 3) / 4) * 4;
+        const int64_t gstride = gmax_stride(nbb);
         const int64_t nchunks = (gstride + kSelChunk - 1) / kSelChunk;
         const int K1 = kprime(kk) + 1;
         const int64_t nslices = (nbb * kRowsPerBlock + kExRows - 1) / kExRows;
@@ -1774,8 +1877,8 @@ struct DenseIndex {
         const int64_t nb = nblocks();
         ScanArgs sa;
         sa.xb = xb.as<float4>(); sa.qf = w.qf.as<float4>(); sa.q = q_dev; sa.norms = norms.as<float>(); sa.gmax = w.gmax.as<float>(); sa.xh = xh.p;
-        sa.gmax2 = sa.gmax + (size_t)w.q * (((2 * w.blocks + 3) / 4) * 4);
-        sa.gstride = ((2 * w.blocks + 3) / 4) * 4; sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
+        sa.gmax2 = sa.gmax + (size_t)w.q * gmax_stride(w.blocks);
+        sa.gstride = gmax_stride(w.blocks); sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
         // operand path: "split" = bf16 hi/lo split MFMAs (default), "f32" = exact-fp32 MFMAs
         const bool split = mode != 0;
         w.split = mode;
@@ -1796,12 +1899,14 @@ struct DenseIndex {
             int nw = 8;   // a third wave per SIMD (12 per workgroup) does not fit 168 registers: 83 spills
             if (P2 % 16 == 0) scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false> : scan_bf16_kernel<METRIC, 8, 16, true>;
             else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 8, false> : scan_bf16_kernel<METRIC, 8, 8, true>;
+            int ch = 8;
+            if (!one_pass && P2 % 16 == 0 && scan_chunk == 16) { scan = scan_bf16_kernel<METRIC, 8, 16, true, 16>; ch = 16; }
             if (scan_waves_small > 0 && P2 % 16 == 0 && nb < (int64_t)scan_cus * 8 * scan_waves_small_blocks) {
                 nw = 4;   // small shard (see scan_waves_small)
                 scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false> : scan_bf16_kernel<METRIC, 4, 16, true>;
             }
             w.waves = nw;
-            w.chunk = 8;
+            w.chunk = nw == 8 ? ch : 8;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(scan_cus), dim3(nw * 64), scan_lds, st, sa);
@@ -1841,7 +1946,7 @@ struct DenseIndex {
     {
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
-        const int64_t gstride = ((2 * w.blocks + 3) / 4) * 4;
+        const int64_t gstride = gmax_stride(w.blocks);
         const int64_t ngroups = nb * 2;
         const int Kp = kprime(k), K1 = Kp + 1;
         const int64_t nchunks = std::max<int64_t>(1, (ngroups + kSelChunk - 1) / kSelChunk);
@@ -1860,9 +1965,9 @@ struct DenseIndex {
         const int64_t sel_slices = (sel_waves + 3) / 4;
         const int64_t wave_cand = sel_slices * 4 * K1;
         if (K1 <= 64 && wave_cand <= (int64_t)kFinWaves * 64 * 16) {
-            // fast selectors: one wave filters kSelPerWave group maxima against its running K1-th best
-            hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)sel_slices, nq), dim3(256), 0, st,
-                               (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>(), fa.dbg);
+            if (!select_by_threshold)   // one wave filters kSelPerWave group maxima against its running K1-th best
+                hipLaunchKernelGGL(select_wave_kernel<false>, dim3((unsigned)sel_slices, nq), dim3(256), 0, st,
+                                   (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>(), fa.dbg);
             fa.ncand = wave_cand;
             u64* fin_base = w.fin.as<u64>();
             fa.sel = fin_base;
@@ -1879,7 +1984,8 @@ struct DenseIndex {
             u64* rb_k = reinterpret_cast<u64*>(rb_sec + (size_t)w.q * kRoundBGroups);
             i64* rb_i = reinterpret_cast<i64*>(rb_k + (size_t)w.q * kRoundBGroups * 4);
             fa.tau = rb_tau; fa.rb_count = rb_count;
-            if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
+            if (select_by_threshold) hipLaunchKernelGGL(fin_select_kernel, dim3(nq), dim3(1024), 0, st, fa, (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups);
+            else if (wave_cand <= 64) hipLaunchKernelGGL((fin_merge_kernel<1, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 128) hipLaunchKernelGGL((fin_merge_kernel<2, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 256) hipLaunchKernelGGL((fin_merge_kernel<4, 1>), dim3(nq), dim3(64), 0, st, fa);
             else if (wave_cand <= 512) hipLaunchKernelGGL((fin_merge_kernel<8, 1>), dim3(nq), dim3(64), 0, st, fa);
