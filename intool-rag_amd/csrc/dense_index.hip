@@ -291,6 +291,29 @@ __device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 
     return m1;
 }
 
+// cnt <= kChunk newest values of a shift chain (block cb + t of the run sits in mh[cnt - 1 - t]) as one run at dst:
+// 16-byte stores when cnt is a multiple of four (small shards: 4 blocks per wave and pass), else value by value.
+// cnt is wave-uniform; dst is 16-byte aligned then (even bpw, chunks of 8 or 16 blocks, h * cnt a multiple of 4).
+template <int kChunk>
+__device__ __forceinline__ void store_run(const float (&mh)[kChunk], int cnt, float* __restrict__ dst)
+{
+    if ((cnt & 3) == 0) {
+#pragma unroll
+        for (int g = 1; g <= kChunk / 4; ++g) {
+            if (cnt == 4 * g) {
+#pragma unroll
+                for (int v = 0; v < g; ++v)
+                    reinterpret_cast<float4*>(dst)[v] = make_float4(mh[4 * g - 1 - 4 * v], mh[4 * g - 2 - 4 * v], mh[4 * g - 3 - 4 * v],
+                                                                    mh[4 * g - 4 - 4 * v]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (t < cnt) dst[cnt - 1 - t] = mh[t];
+    }
+}
+
 // Park one block's lane maximum in a 16-register shift chain (mh[0] = newest); on the last block of a chunk (or of the
 // wave's range) write the chunk out as one run per lane.  Registers, not LDS: the query tile already takes 128 KiB.
 // Plain stores: with the ring loads hidden in asm they are the only VMEM ops hipcc sees here, so they never
@@ -314,9 +337,7 @@ __device__ __forceinline__ void park_and_flush(float (&mh)[kChunk], float m, int
             reinterpret_cast<float4*>(dst)[v] = make_float4(mh[kChunk - 1 - 4 * v], mh[kChunk - 2 - 4 * v], mh[kChunk - 3 - 4 * v],
                                                             mh[kChunk - 4 - 4 * v]);
     } else {
-#pragma unroll
-        for (int t = 0; t < kChunk; ++t)
-            if (t < cnt) dst[cnt - 1 - t] = mh[t];
+        store_run(mh, cnt, dst);
     }
 }
 
@@ -360,10 +381,7 @@ __device__ __forceinline__ void flush_partial(const float (&mh)[kChunk], int cnt
                                               int qoff, int64_t cb)
 {
     const int h = lane >> 5, qb = (lane & 31) + qoff;
-    float* dst = gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * cnt;
-#pragma unroll
-    for (int t = 0; t < kChunk; ++t)
-        if (t < cnt) dst[cnt - 1 - t] = mh[t];
+    store_run(mh, cnt, gm + (int64_t)qb * gstride + 2 * cb + (int64_t)h * cnt);
 }
 
 template <int METRIC, int NWAVES, int RING = 16>
@@ -569,7 +587,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         u32x4* qhi_w = reinterpret_cast<u32x4*>(qs);
         u32x4* qlo_w = qhi_w + npairs * 64;
         const bool vec_ok = (a.d & 3) == 0;
-        for (int idx = tid; idx < npairs * 64; idx += NT) {
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));   // (see scan_bf16_kernel: keeps per-thread address arithmetic out of the pass loop's live set)
+        for (int idx = tid_p; idx < npairs * 64; idx += NT) {
             const int pp = idx >> 6, l = idx & 63;
             const int hh = l >> 5;
             unsigned hA[4], lA[4], hB[4];
@@ -662,22 +682,25 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         }
         if (METRIC == HIPRAG_METRIC_L2)
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
+        const int h_b = lane_b >> 5;
         if (QT == 1) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = acc_hi[i] + acc_lo[i];
             float sec;
-            const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h, a, sec);
-            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
+            const float fst = block_lane_top2<METRIC>(acc, nrm, blk, h_b, a, sec);
+            park_and_flush(mh[0], fst, blk, b0, b1, lane_b, a.gmax, a.gstride, qbase);
+            park_and_flush(ms[0], sec, blk, b0, b1, lane_b, a.gmax2, a.gstride, qbase);
         } else {
             float sec;
-            float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h, a, sec);
-            park_and_flush(mh[0], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase);
-            park_and_flush(ms[0], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase);
-            fst = block_lane_top2<METRIC>(acc_lo, nrm, blk, h, a, sec);
-            park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane, a.gmax, a.gstride, qbase + 32);
-            park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane, a.gmax2, a.gstride, qbase + 32);
+            float fst = block_lane_top2<METRIC>(acc_hi, nrm, blk, h_b, a, sec);
+            park_and_flush(mh[0], fst, blk, b0, b1, lane_b, a.gmax, a.gstride, qbase);
+            park_and_flush(ms[0], sec, blk, b0, b1, lane_b, a.gmax2, a.gstride, qbase);
+            fst = block_lane_top2<METRIC>(acc_lo, nrm, blk, h_b, a, sec);
+            park_and_flush(mh[QT - 1], fst, blk, b0, b1, lane_b, a.gmax, a.gstride, qbase + 32);
+            park_and_flush(ms[QT - 1], sec, blk, b0, b1, lane_b, a.gmax2, a.gstride, qbase + 32);
         }
     }
     }  // pass
@@ -1900,7 +1923,7 @@ struct DenseIndex {
             if (P2 % 16 == 0) scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false> : scan_bf16_kernel<METRIC, 8, 16, true>;
             else scan = one_pass ? scan_bf16_kernel<METRIC, 8, 8, false> : scan_bf16_kernel<METRIC, 8, 8, true>;
             int ch = 8;
-            if (!one_pass && P2 % 16 == 0 && scan_chunk == 16) { scan = scan_bf16_kernel<METRIC, 8, 16, true, 16>; ch = 16; }
+            if (P2 % 16 == 0 && scan_chunk == 16) { scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false, 16> : scan_bf16_kernel<METRIC, 8, 16, true, 16>; ch = 16; }
             if (scan_waves_small > 0 && P2 % 16 == 0 && nb < (int64_t)scan_cus * 8 * scan_waves_small_blocks) {
                 nw = 4;   // small shard (see scan_waves_small)
                 scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false> : scan_bf16_kernel<METRIC, 4, 16, true>;
@@ -1915,8 +1938,11 @@ struct DenseIndex {
             const bool one_pass = nq <= pass_queries_for(k);
             if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 1, kChunk, false>;
             if (mode == 2) {                                                             // 64 queries, hi-only query tiles
-                scan = scan_split_kernel<METRIC, 8, 16, 2, 8>; w.chunk = 8;
-                if (one_pass) scan = scan_split_kernel<METRIC, 8, 16, 2, 8, false>;
+                if (scan_chunk == 16) {   // whole 128-byte lines per flush (see flush_full)
+                    scan = one_pass ? scan_split_kernel<METRIC, 8, 16, 2, 16, false> : scan_split_kernel<METRIC, 8, 16, 2, 16>; w.chunk = 16;
+                } else {
+                    scan = one_pass ? scan_split_kernel<METRIC, 8, 16, 2, 8, false> : scan_split_kernel<METRIC, 8, 16, 2, 8>; w.chunk = 8;
+                }
             }
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
