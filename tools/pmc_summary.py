@@ -6,8 +6,8 @@ import csv, glob, json, sys
 def collect(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and ("scan_bf16_kernel" in r["Kernel_Name"] or "scan_split_kernel" in r["Kernel_Name"]) and ", true>" in r["Kernel_Name"]]
-    # ", true>" = the multi-pass form of the template (single-query callers get the ", false>" form)
+            if r["Counter_Name"] == counter and ("scan_bf16_kernel" in r["Kernel_Name"] or "scan_split_kernel" in r["Kernel_Name"]) and ", true" in r["Kernel_Name"]]
+    # ", true" = the multi-pass form of the template (single-query callers get the ", false" form)
     vals = vals[3:]          # drop the first launches
     return {"launches": len(vals), "mean_kb": sum(vals) / len(vals), "min_kb": min(vals), "max_kb": max(vals)}
 
