@@ -117,6 +117,74 @@ def test_config2_1m_chunks_hybrid_bit_exact(gpu):
     assert np.array_equal(hi, efi) and np.array_equal(hs, efs)
     assert index.stats()["fallback_queries"] == 0
 
+    # configs[3]'s structure on this collection: rows AND postings split by the same eight document ranges (125 k-row
+    # shards run the small-shard form of the scan), both partial lists of every shard merged globally, RRF after the
+    # merge -- the fused lists must be the unsharded ones, bit for bit
+    from hiprag.sharded import EmulatedHybridShards, shard_bounds
+    index.close()
+    del bm25
+    bounds = shard_bounds(N, 8)
+    shards = []
+    for lo, hi_ in bounds:
+        ix = HipFlatIndex(d, "ip")
+        ix.add(xh[lo:hi_])
+        shards.append((ix, HipBM25(p.shard(lo, hi_))))
+    ss, si = EmulatedHybridShards(shards, bounds).search_device(qd, queries, depth=depth, k=k)
+    torch.cuda.synchronize()
+    assert np.array_equal(si.cpu().numpy(), efi) and np.array_equal(ss.cpu().numpy(), efs)
+    assert all(ix.stats()["fallback_queries"] == 0 for ix, _ in shards)
+
+
+def test_config3_10m_rows_eight_shards_on_one_gpu(gpu):
+    """configs[3] at full size, minus the wire: 10M x 1024 rows as EIGHT 1.25M-row shards (what each of the 8 GPUs holds),
+    all on this one device, searched shard by shard and merged by the same canonical merge the all-gather feeds
+    (EmulatedShards).  Checked against an independent fp64 brute force over all ten million rows (torch on the GPU, rows
+    regenerated from their seeds), ids exact, scores to 1e-12; planted neighbours -- the first and last row of every
+    shard among them -- must come out on top.  61 GB of HBM for the index."""
+    import torch
+    from hiprag import HipFlatIndex
+    from hiprag.sharded import EmulatedShards, shard_bounds
+    dev = torch.device("cuda", 0)
+    N, d, k, chunk, world = 10_000_000, 1024, 10, 125_000, 8
+    bounds = shard_bounds(N, world)
+    assert all(lo % chunk == 0 for lo, _ in bounds)
+    shards = []
+    for lo, hi in bounds:
+        ix = HipFlatIndex(d, "ip")
+        for c in range(lo // chunk, hi // chunk):
+            ix.add_device(_gpu_rows(torch, dev, c, chunk, d))
+        assert ix.ntotal == hi - lo
+        shards.append(ix)
+    torch.cuda.synchronize()
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    q = torch.randn((96, d), generator=g, device=dev)
+    q /= q.norm(dim=1, keepdim=True)
+    planted = sorted({lo for lo, _ in bounds} | {hi - 1 for _, hi in bounds} | {123_457, 4_999_999, 7_654_321, 9_876_543})
+    for j, r in enumerate(planted):      # queries 0..: a row plus a little noise -> that row is the nearest neighbour
+        x = _gpu_rows(torch, dev, r // chunk, chunk, d)[r % chunk]
+        v = x + 0.02 * q[j]
+        q[j] = v / v.norm()
+    s64, s32, ids = EmulatedShards(shards, bounds).search_device(q, k)
+    torch.cuda.synchronize()
+    assert torch.equal(ids[:len(planted), 0].cpu(), torch.tensor(planted))
+
+    q64 = q.double()
+    best_s = torch.full((q.shape[0], k), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=dev)
+    for c in range(N // chunk):
+        sc = q64 @ _gpu_rows(torch, dev, c, chunk, d).double().T          # [96, chunk]
+        cs, ci = torch.topk(sc, k, dim=1)
+        allS = torch.cat([best_s, cs], 1)
+        allI = torch.cat([best_i, ci + c * chunk], 1)
+        order = torch.argsort(allS, dim=1, descending=True, stable=True)[:, :k]   # earlier (lower) ids first among equals
+        best_s, best_i = torch.gather(allS, 1, order), torch.gather(allI, 1, order)
+    assert torch.equal(ids, best_i), torch.nonzero((ids != best_i).any(1)).ravel()[:8]
+    assert torch.allclose(s64, best_s, rtol=0, atol=1e-12)
+    assert torch.all(s64[:, :-1] >= s64[:, 1:])
+    assert all(ix.stats()["fallback_queries"] == 0 for ix in shards)
+
 
 @pytest.fixture(scope="module")
 def xlmr_large():
