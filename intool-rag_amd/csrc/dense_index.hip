@@ -40,6 +40,11 @@ namespace {
 constexpr int kRowsPerBlock = 32;
 constexpr int kPieceFloats = 256;
 constexpr int kPieceVec4 = 64;
+// Position (in float4 units) inside a 1 KiB piece of the four k-values [8p + 4h, 8p + 4h + 4) of row r of the block:
+// quad-major, so that the 4 rows x 2 halves of a row QUAD are one contiguous 128-byte line of every piece -- the unit the
+// fp64 re-score reads (fin_rescore: 128 whole lines per quad instead of 256 half lines 512 bytes apart).  The fp32 scans
+// read whole pieces and only permute which lane takes which 16 bytes.
+__host__ __device__ __forceinline__ int piece_slot(int h, int r) { return ((r >> 2) << 3) | (h << 2) | (r & 3); }
 // a PASS = the queries that share one read of the index: 32 (full hi/lo or fp32 operands) or 64 (hi-only query tiles)
 constexpr int kMaxQ = 1024;        // most queries per LAUNCH (16 passes of 64): see DenseIndex::update_launch_q
 constexpr int kMaxScanWaves = 12;  // stamp slots per scan workgroup
@@ -82,7 +87,7 @@ __global__ void retile_kernel(const float* __restrict__ src, int64_t row0, int64
     v.y = col + 1 < d ? s[1] : 0.f;
     v.z = col + 2 < d ? s[2] : 0.f;
     v.w = col + 3 < d ? s[3] : 0.f;
-    xb[(blk * P + p) * kPieceVec4 + lane] = v;
+    xb[(blk * P + p) * kPieceVec4 + piece_slot(h, r)] = v;
 }
 
 __global__ void untile_kernel(const float4* __restrict__ xb, int64_t row0, int64_t n, int d, int P,
@@ -96,7 +101,7 @@ __global__ void untile_kernel(const float4* __restrict__ xb, int64_t row0, int64
     const int p = ph >> 1, h = ph & 1;
     const int64_t blk = row / kRowsPerBlock;
     const int r = (int)(row % kRowsPerBlock);
-    float4 v = xb[(blk * P + p) * kPieceVec4 + h * 32 + r];
+    float4 v = xb[(blk * P + p) * kPieceVec4 + piece_slot(h, r)];
     const int col = 8 * p + 4 * h;
     float* o = dst + (row - row0) * (int64_t)d + col;
     if (col + 0 < d) o[0] = v.x;
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_kernel(ScanArgs a)
     float mh[kChunk], ms[kChunk];  // lane first / second values of the current chunk (shift chains)
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) { mh[t] = 0.f; ms[t] = 0.f; }
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lane16 = (unsigned)piece_slot(lane >> 5, lane & 31) * 16u;   // this lane's 16 bytes of a piece (A fragment of row lane & 31)
     const int h = lane >> 5;
 
     // The X stream is driven by hand: loads are inline asm (invisible to hipcc's waitcnt pass, which otherwise drains
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     for (int t = 0; t < CH; ++t)
 #pragma unroll
         for (int u = 0; u < QT; ++u) { mh[u][t] = 0.f; ms[u][t] = 0.f; }
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lane16 = (unsigned)piece_slot(lane >> 5, lane & 31) * 16u;   // this lane's 16 bytes of a piece (A fragment of row lane & 31)
     const int h = lane >> 5;
 
     f32x4 ring[RING];
@@ -906,7 +911,7 @@ __device__ __forceinline__ double rescore4(const float4* __restrict__ xb, int P,
 {
     const int lane = threadIdx.x & 63;
     const int rr = lane & 3, hh = (lane >> 2) & 1, pq = lane >> 3;
-    const float4* src = xb + blk * P * kPieceVec4 + hh * 32 + r0 + rr;
+    const float4* src = xb + blk * P * kPieceVec4 + piece_slot(hh, r0 + rr);
     // P <= 128 (LDS limit of the scan), so a lane touches at most 16 pieces.  Loads go out in batches of 8 before their
     // first use: a dependent-latency loop here costs an HBM round trip per piece and used to dominate the finish kernel;
     // all 16 at once spills at the 128-VGPR budget of the 16-wave finish workgroup.  (P >= 1: d >= 1.)
