@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--legs", default="fp32,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: run the multi-GPU code path (process group, all-gather per step, merge) on ONE rank, "
+                         "so that a one-GPU box executes the RCCL calls of the N > 1 run")
     args = ap.parse_args()
 
     import torch
@@ -231,7 +234,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["HIPRAG_FORCE_EXCHANGE"] = "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_gpu:
             local_rank = 0
@@ -298,7 +312,7 @@ def main():
         return last
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -316,7 +330,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st = index.stats()
     index.enable_timing(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -344,13 +358,13 @@ def main():
     lat_dev = np.sort(np.asarray(lat_dev[20:]))
 
     rows_local = [int(index.ntotal)]
-    if world > 1:      # what every rank holds, as seen by the collective: lets a reader check that N ranks really took part
+    if use_dist:      # what every rank holds, as seen by the collective: lets a reader check that N ranks really took part
         seen = [None] * world
         dist.all_gather_object(seen, (rank, int(index.ntotal), int(row_lo), int(sharded.max_pass)))
         rows_local = [v[1] for v in sorted(seen)]
         assert sum(rows_local) == n_rows and all(v[3] == sharded.max_pass for v in seen), seen
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -377,10 +391,10 @@ def main():
                    "rows": n_rows, "dim": DIM, "k": TOPK, "queries_per_step": BATCH, "passes_per_step": PASSES,
                    "queries_per_pass": index.pass_queries,
                    "sharding": f"rows/{world}" if world > 1 else "none",
-                   "exchange": f"1 all-gather of [2,{BATCH},{TOPK}] int64 per step" if world > 1 else "none",
+                   "exchange": f"1 all-gather of [2,{BATCH},{TOPK}] int64 per step" if use_dist else "none",
                    "steps_in_flight": IN_FLIGHT, "world": world, "rows_local": rows_local,
-                   "backend": (args.backend if world > 1 else "none"),
-                   "allgather_payload_bytes_per_rank": (2 * BATCH * TOPK * 8 if world > 1 else 0)},
+                   "backend": (args.backend if use_dist else "none"),
+                   "allgather_payload_bytes_per_rank": (2 * BATCH * TOPK * 8 if use_dist else 0)},
         "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),
@@ -453,7 +467,7 @@ def main():
         del sharded
         out["legs"] = run_legs(torch, args, dev, index, queries, [v.strip() for v in args.legs.split(",") if v.strip()])
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,6 +43,11 @@ def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
     return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
 
 
+def _exchange_on(world: int) -> bool:
+    import torch.distributed as dist
+    return world > 1 or (dist.is_initialized() and os.environ.get("HIPRAG_FORCE_EXCHANGE") == "1")
+
+
 def agree_min(value: int, device: int, group=None) -> int:
     """MIN of an integer over the ranks of `group` (one small all-reduce, at construction time only)."""
     import torch
@@ -70,8 +75,11 @@ class ShardedFlatIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # the exchange (one all-gather per batch + merge) runs whenever there is more than one rank;
+        # HIPRAG_FORCE_EXCHANGE=1 runs it on a one-rank group as well (a single-GPU box can then exercise the RCCL calls)
+        self.exchange = _exchange_on(self.world)
         local.set_id_base(row_lo)
-        if self.world > 1 and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+        if self.exchange and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
             # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
             # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
             local.set_spare_cus(8)
@@ -84,8 +92,8 @@ class ShardedFlatIndex:
         self._slot_ended = [False] * N_SLOTS
         self._bufs = [dict() for _ in range(N_SLOTS)]
         self._scan_done = [torch.cuda.Event() for _ in range(N_SLOTS)]
-        self._max_pass = agree_min(local.launch_queries, local.device, group) if self.world > 1 else None
-        self._check_shapes = self.world > 1 and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
+        self._max_pass = agree_min(local.launch_queries, local.device, group) if self.exchange else None
+        self._check_shapes = self.exchange and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
 
     @property
     def max_pass(self) -> int:
@@ -109,10 +117,10 @@ class ShardedFlatIndex:
             cache["pack"] = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
             cache["s32"] = torch.empty((nq, k), dtype=torch.float32, device=dev)
             cache["gathered"] = (torch.empty((self.world, 2, nq, k), dtype=torch.int64, device=dev)
-                                 if self.world > 1 else None)
+                                 if self.exchange else None)
             cache["merged"] = ((torch.empty((nq, k), dtype=torch.float64, device=dev),
                                 torch.empty((nq, k), dtype=torch.float32, device=dev),
-                                torch.empty((nq, k), dtype=torch.int64, device=dev)) if self.world > 1 else None)
+                                torch.empty((nq, k), dtype=torch.int64, device=dev)) if self.exchange else None)
             cache["scanned"], cache["done"], cache["fin"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         return cache
 
@@ -140,7 +148,7 @@ class ShardedFlatIndex:
             if self._slot_used[slot] and not self._slot_ended[slot]:
                 # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
                 # waited there and stream order covers it (one barrier packet less per step)
-                main.wait_event(c["fin"] if self.world > 1 else c["done"])
+                main.wait_event(c["fin"] if self.exchange else c["done"])
             self.local.search_begin(q, k, slot, stream=main.cuda_stream)
             c["scanned"].record(main)
             side.wait_event(c["scanned"])
@@ -157,7 +165,7 @@ class ShardedFlatIndex:
         self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=self._side_ptr[slot])
         c["done"].record(side)
         work = None
-        if self.world > 1:
+        if self.exchange:
             with torch.cuda.stream(side):
                 work = all_gather_packed(pack, c["gathered"], self.group, async_op=True)
         return (work, slot, k)
@@ -271,12 +279,13 @@ class ShardedHybrid:
         import torch.distributed as dist
         self.dense, self.bm25, self.group = dense, bm25, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = _exchange_on(self.world)     # see ShardedFlatIndex
         dense.set_id_base(row_lo)
         bm25.set_id_base(row_lo)
-        if self.world > 1 and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+        if self.exchange and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
             dense.set_spare_cus(8)          # room for the all-gather kernel beside the next scan (ShardedFlatIndex)
-        self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.world > 1 else None
-        self._check_shapes = self.world > 1 and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
+        self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.exchange else None
+        self._check_shapes = self.exchange and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
         self.side = [torch.cuda.Stream(device=dense.device) for _ in range(N_SLOTS)]
         self._side_ptr = [st.cuda_stream for st in self.side]
         self._slot = 0
@@ -300,7 +309,7 @@ class ShardedHybrid:
             c["pack"] = torch.empty((2, 2, nq, depth), dtype=torch.int64, device=dev)       # [leg, {score bits, ids}, nq, depth]
             c["s32"] = torch.empty((2, nq, depth), dtype=torch.float32, device=dev)
             c["gathered"] = (torch.empty((self.world, 2, 2, nq, depth), dtype=torch.int64, device=dev)
-                             if self.world > 1 else None)
+                             if self.exchange else None)
             c["legs"] = [(torch.empty((nq, depth), dtype=torch.float64, device=dev),
                           torch.empty((nq, depth), dtype=torch.float32, device=dev),
                           torch.empty((nq, depth), dtype=torch.int64, device=dev)) for _ in range(2)]
@@ -334,7 +343,7 @@ class ShardedHybrid:
         work = None
         with torch.cuda.stream(side):
             self.bm25.search_device(sparse_queries, depth, out=(pack[1, 0].view(torch.float64), b["s32"][1], pack[1, 1]))
-            if self.world > 1:
+            if self.exchange:
                 work = all_gather_packed(pack, b["gathered"], self.group, async_op=True)
         return (work, slot, depth, k, c, w_dense, w_sparse)
 
@@ -349,7 +358,7 @@ class ShardedHybrid:
         with torch.cuda.stream(side):
             if work is not None:
                 work.wait()
-            g = b["gathered"] if self.world > 1 else b["pack"].unsqueeze(0)
+            g = b["gathered"] if self.exchange else b["pack"].unsqueeze(0)
             dl = merge_topk_device(g[:, 0, 0].view(torch.float64), g[:, 0, 1], depth, self.dense.metric, out=b["legs"][0])
             sl = merge_topk_device(g[:, 1, 0].view(torch.float64), g[:, 1, 1], depth, METRIC_IP, out=b["legs"][1])
             out = rrf_fuse_device(dl[2], sl[2], k, c, w_dense, w_sparse, out=b["fused"])

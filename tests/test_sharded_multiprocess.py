@@ -222,3 +222,74 @@ def test_bench_rehearsal_two_ranks_under_torch_distributed_run(gpu):
     assert d["n_gpus"] == 2 and d["config"]["world"] == 2 and d["config"]["rows_local"] == [64000, 64000]
     assert d["config"]["backend"] == "gloo" and d["config"]["allgather_payload_bytes_per_rank"] > 0
     assert d["value"] > 0 and d["fallback_queries"] == 0 and "legs" not in d and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_over_rccl_runs_the_exchange_path(gpu):
+    """The calls of the N > 1 run that a one-GPU box CAN execute on RCCL itself: bench.py --force-dist initialises the
+    `nccl` process group with one rank (device_id form), agrees the launch size by all-reduce, and runs the per-step
+    all_gather_into_tensor (async, on the slot streams) + merge of ShardedFlatIndex, the barriers, the MAX all-reduce of the
+    elapsed time and all_gather_object -- everything but a second GPU on the wire.  Results must still be the exact ones
+    (bench.py compares sampled ids with the CPU port when the baseline is on; here: no fallbacks, sane line)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "6",
+           "--warmup", "2", "--rows", "256000", "--legs", "none", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["backend"] == "nccl" and d["config"]["world"] == 1 and d["config"]["rows_local"] == [256000]
+    assert d["config"]["allgather_payload_bytes_per_rank"] > 0 and d["value"] > 0 and d["fallback_queries"] == 0
+
+
+def _rccl_one_rank_worker(rank, world, port, q_out):
+    """ShardedFlatIndex and ShardedHybrid with the exchange forced on a one-rank RCCL group: sharded == oracle."""
+    import torch
+    for p in (REPO, os.path.join(REPO, "intool-rag_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HIPRAG_FORCE_EXCHANGE="1",
+                      HIPRAG_CHECK_SHAPES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HIPRAG_LAUNCH_QUERIES="64")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from hiprag import HipBM25, HipFlatIndex, PostingsCSR
+    from hiprag.sharded import ShardedFlatIndex, ShardedHybrid
+    from oracle import hybrid_oracle as ho
+    try:
+        n, d, depth, k, nq = 9001, 128, 50, 10, 150
+        x = ho.synthetic_vectors(n, d, seed=91)
+        q = ho.synthetic_queries(nq, d, seed=92)
+        qd = torch.from_numpy(q).cuda()
+        local = HipFlatIndex(d, "ip")
+        local.add(x)
+        sh = ShardedFlatIndex(local, 0)
+        assert sh.exchange and sh.world == 1 and sh.max_pass == 64
+        s64, s32, ids = sh.search_device(qd, k)          # three pipelined pieces, one all-gather each
+        torch.cuda.synchronize()
+        es, ei = ho.flat_search(x, q, k, ho.METRIC_IP)
+        assert np.array_equal(ids.cpu().numpy(), ei) and np.array_equal(s32.cpu().numpy(), es)
+        p = ho.synthetic_postings(n, n_terms=512, seed=93)
+        sq = ho.synthetic_sparse_queries(nq, n_terms=512, terms_per_query=5, seed=94, min_rank=4)
+        hy = ShardedHybrid(local, HipBM25(PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts)), 0)
+        assert hy.exchange
+        fs, fi = hy.search_device(qd, sq, depth=depth, k=k)
+        torch.cuda.synchronize()
+        _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
+        _, bi = ho.bm25_search(p, sq, depth)
+        efs, efi = ho.rrf_fuse(di, bi, k)
+        assert np.array_equal(fi.cpu().numpy(), efi) and np.array_equal(fs.cpu().numpy(), efs)
+        q_out.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q_out.put((rank, repr(e) + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_classes_on_a_one_rank_rccl_group(gpu):
+    _run(_rccl_one_rank_worker, world=1, timeout=300)
