@@ -43,6 +43,21 @@ def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
     return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
 
 
+def _slot_streams(device):
+    """The streams the tails of the N_SLOTS workspace slots run on: HIPRAG_SIDE_STREAMS of them (default 2), the slots
+    taking turns.  HIP maps streams onto four hardware queues and streams that share a queue execute in submission order:
+    with one stream per slot a third of the slots shared the queue of the caller's stream (or of RCCL's), and every such
+    step ran its tail -- and the all-gather behind it -- BEFORE the next scan instead of beside it.  Caller's stream + two
+    tail streams + RCCL's stream = four queues, nothing shared; more hardware queues (GPU_MAX_HW_QUEUES = 8 / 16, or
+    high-priority tail streams, which come from a second queue pool) are time-sliced and lengthen the gap between launches
+    two- to fivefold instead.  Measured on a 125 k-row shard with the exchange on (one-rank RCCL group): 1.04 M queries/s
+    with eight tail streams, 1.14-1.19 M with two."""
+    import torch
+    n = max(1, min(N_SLOTS, int(os.environ.get("HIPRAG_SIDE_STREAMS", "2"))))
+    pool = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return [pool[i % n] for i in range(N_SLOTS)]
+
+
 def _exchange_on(world: int) -> bool:
     import torch.distributed as dist
     return world > 1 or (dist.is_initialized() and os.environ.get("HIPRAG_FORCE_EXCHANGE") == "1")
@@ -83,9 +98,11 @@ class ShardedFlatIndex:
             # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
             # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
             local.set_spare_cus(8)
-        # one side stream per workspace slot: the tail of batch i (finish -> all-gather -> merge) must not queue behind
-        # the tail of batch i+1, which cannot start before scan i+1 ends
-        self.side = [torch.cuda.Stream(device=local.device) for _ in range(N_SLOTS)]
+        # the tails (finish -> all-gather -> merge) run on two streams that the slots take turns on (_slot_streams): the
+        # tail of batch i never queues behind that of batch i+1, which cannot start before scan i+1 ends; its merge,
+        # enqueued at search_end, may sit behind the finish of batch i+2 -- a scan that is ahead of it on the caller's
+        # stream anyway
+        self.side = _slot_streams(local.device)
         self._side_ptr = [st.cuda_stream for st in self.side]
         self._slot = 0
         self._slot_used = [False] * N_SLOTS
@@ -286,7 +303,7 @@ class ShardedHybrid:
             dense.set_spare_cus(8)          # room for the all-gather kernel beside the next scan (ShardedFlatIndex)
         self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.exchange else None
         self._check_shapes = self.exchange and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
-        self.side = [torch.cuda.Stream(device=dense.device) for _ in range(N_SLOTS)]
+        self.side = _slot_streams(dense.device)
         self._side_ptr = [st.cuda_stream for st in self.side]
         self._slot = 0
         self._used = [False] * N_SLOTS
