@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(64) void roundb_final_kernel(RoundBArgs a)
 // path: exact, just not fast -- k in the hundreds is outside anything the reference asks for (top_chunks = 50).
 __global__ void flag_all_kernel(int* flags, int* arrivals, unsigned long long* fallback_counter, int nq)
 {
-    const int q = threadIdx.x;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nq) {
         flags[q] = 1;
         arrivals[q] = 0;
@@ -2035,7 +2035,7 @@ struct DenseIndex {
             hipLaunchKernelGGL(roundb_rescore_kernel<METRIC>, dim3(8, nq), dim3(256), (size_t)P * 8 * sizeof(float), st, rb);
             hipLaunchKernelGGL(roundb_final_kernel<METRIC>, dim3(nq), dim3(64), 0, st, rb);
         } else if ((int64_t)Kp * 16 > kSelChunk) {
-            hipLaunchKernelGGL(flag_all_kernel, dim3(1), dim3(kMaxQ), 0, st, flags, arrivals, fallback_counter(), nq);
+            hipLaunchKernelGGL(flag_all_kernel, dim3((kMaxQ + 1023) / 1024), dim3(1024), 0, st, flags, arrivals, fallback_counter(), nq);
         } else {
             hipLaunchKernelGGL(select_f32_kernel<false>, dim3((unsigned)nchunks, nq), dim3(kSelThreads), 0, st,
                                (const float*)w.gmax.as<float>(), (i64)gstride, (i64)ngroups, K1, w.ck.as<u64>(), w.ci.as<i64>());
