@@ -16,6 +16,10 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 150):
     metric = [ho.METRIC_IP, ho.METRIC_L2][case % 2]
     mode = ["bf16", "bf16", "bf16", "q64", "split", "f32"][int(rng.integers(6))]
     os.environ["HIPRAG_SCAN_MODE"]=mode
+    # few scan workgroups -> many blocks per wave at these small sizes: full 16-block chunks, several chunks per wave and
+    # pass, short last chunks of every length (the flush paths a 1M-row index takes with the whole grid)
+    os.environ["HIPRAG_SCAN_SPARE_CUS"]=str(int(rng.choice([0, 0, 192, 240, 252, 254])))
+    os.environ["HIPRAG_SCAN_CHUNK"]=str(int(rng.choice([16, 16, 8])))
     x = ho.synthetic_vectors(n, d, seed=5000 + case); q = ho.synthetic_queries(nq, d, seed=6000 + case)
     if case % 3 == 0: x *= rng.uniform(0.1, 30.0, size=(n, 1)).astype(np.float32)
     if case % 4 == 1 and n > 40: x[rng.integers(0, n, size=20)] = x[3]
