@@ -231,8 +231,12 @@ constexpr int kChunk = 16;        // blocks per flush of the fp32 scan and the d
 
 __host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks, int64_t nwaves)
 {
-    const int64_t bpw = (nblocks + nwaves - 1) / nwaves;
-    return (bpw + 1) & ~(int64_t)1;  // even, so every chunk base is even and 16-value runs are 16-byte aligned
+    int64_t bpw = (nblocks + nwaves - 1) / nwaves;
+    bpw = (bpw + 1) & ~(int64_t)1;   // even, so every chunk base is even and 16-value runs are 16-byte aligned
+    // whole 16-block chunks (= whole, aligned 128-byte lines of output per query and flush) where that idles few waves
+    const int64_t r16 = (bpw + 15) & ~(int64_t)15;
+    if (bpw > 16 && r16 * 100 <= bpw * 106) bpw = r16;
+    return bpw;
 }
 
 // slot -> (block, lane half); inverse of the permutation above.  bpw = scan_blocks_per_wave(nblocks, waves of the scan).
@@ -1839,11 +1843,13 @@ struct DenseIndex {
     // Small shards (an 8-GPU row split of 1M rows leaves 125 k per GPU): with 8 waves per workgroup a wave streams two or
     // three 32-row blocks per pass; 4-wave workgroups stream twice as many each and leave half of every SIMD's registers to
     // the tail kernels of earlier steps.  Measured (1024 queries per launch, pipelined): 125 k rows 945 -> 902 us per step,
-    // 250 k 1640 -> 1590, 500 k 2758 -> 2857 (slower), 1M equal -- so below 5 blocks per wave of the 8-wave partition.
+    // 250 k 1640 -> 1590, 500 k 2758 -> 2857 (slower), 1M equal -- so below 5 blocks per wave of the 8-wave partition in
+    // round 1.  With 16-block flushes the 4-wave form writes whole lines at 500 k rows (16 blocks per wave and pass) where
+    // the 8-wave form writes half lines: 345 -> 353 k queries/s, so the rule now reaches 9 blocks per wave (~590 k rows).
     bool select_by_threshold = true;   // HIPRAG_SELECT=wave: the per-wave selectors (select_wave_kernel) instead
     int scan_chunk = 16;               // HIPRAG_SCAN_CHUNK: blocks per flush of the multi-pass bf16 scan (16 = whole 128-byte lines)
     int scan_waves_small = 1;          // HIPRAG_SCAN_WAVES_SMALL=0 keeps 8 waves everywhere
-    int scan_waves_small_blocks = 5;   // HIPRAG_SCAN_WAVES_SMALL_BLOCKS
+    int scan_waves_small_blocks = 9;   // HIPRAG_SCAN_WAVES_SMALL_BLOCKS
     int mode_for(int k) const { return (scan_mode >= 2 && k > kMaxK64) ? 1 : scan_mode; }
     int pass_queries_for(int k) const { return mode_for(k) >= 2 ? 64 : 32; }
     // groups re-scored per query: the hi-only query tiles of the 64-query mode widen eps to 2^-9 |q||x|, so keep more
@@ -1931,10 +1937,11 @@ struct DenseIndex {
             if (P2 % 16 == 0 && scan_chunk == 16) { scan = one_pass ? scan_bf16_kernel<METRIC, 8, 16, false, 16> : scan_bf16_kernel<METRIC, 8, 16, true, 16>; ch = 16; }
             if (scan_waves_small > 0 && P2 % 16 == 0 && nb < (int64_t)scan_cus * 8 * scan_waves_small_blocks) {
                 nw = 4;   // small shard (see scan_waves_small)
-                scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false> : scan_bf16_kernel<METRIC, 4, 16, true>;
+                if (scan_chunk == 16) scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false, 16> : scan_bf16_kernel<METRIC, 4, 16, true, 16>;
+                else { scan = one_pass ? scan_bf16_kernel<METRIC, 4, 16, false> : scan_bf16_kernel<METRIC, 4, 16, true>; ch = 8; }
             }
             w.waves = nw;
-            w.chunk = nw == 8 ? ch : 8;
+            w.chunk = ch;
             { int32_t lrc = ensure_lds(reinterpret_cast<const void*>(scan), scan_lds); if (lrc) return lrc; }
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev], st));
             if (nb > 0) hipLaunchKernelGGL(scan, dim3(scan_cus), dim3(nw * 64), scan_lds, st, sa);
