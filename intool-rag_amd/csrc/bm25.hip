@@ -62,14 +62,16 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 
 // ---------------------------------------------------------------------------------------------------------
 // Tiled TAAT (the default path, k <= 64): one workgroup per (document tile, query) keeps the tile's fp32 accumulators in
-// LDS (12288 documents = 48 KiB: THREE workgroups per CU; 16384-document tiles left room for two and ran 12 % slower,
-// 13312 fit three on paper only), walks the query's term slots IN ORDER -- for each slot it streams only the postings
+// LDS (9216 documents = 36 KiB: FOUR workgroups per CU.  A workgroup spends its ~17 us mostly waiting -- six term slots x
+// (barrier + LDS read-modify-write round trip), then the pass over the accumulators -- so workgroups per CU are the lever:
+// 16384-document tiles (two per CU) 370 k queries/s at 1M documents, 12288 (three) 400-418 k, 9216 (four) 411-417 k, 8192
+// (four, more tiles) 398 k; 13312 fit three on paper only), walks the query's term slots IN ORDER -- for each slot it streams only the postings
 // whose document falls into the tile -- and then selects the tile's top-k straight out of LDS.  HBM traffic is the posting
 // streams alone: no accumulator array to zero, scatter into and scan again (the global-accumulator form below moves
 // 8 B per posting plus up to two 128-B lines per touched accumulator through L2, and ran at ~1.2 TB/s).
 // Where a list's tile range starts comes from a SKIP TABLE built at create time for every list with >= kSkipMinDf
 // postings (the posting offset at each tile boundary, u32 relative to the list start, (ntiles + 1) entries); shorter
-// lists are read whole by every tile and filtered -- 82 tiles x < 2048 postings costs less than a table lookup chain.
+// lists are read whole by every tile and filtered -- 109 tiles x < 2048 postings costs less than a table lookup chain.
 // Determinism: a document occurs at most once per list, so within a slot no two threads touch the same accumulator and
 // the barrier between slots keeps every document's fp32 sum in query-term order, exactly the oracle's.
 // Selection: grid (nq, ntiles), queries fastest.  theta[q] (zeroed per launch) carries the best K-th score any finished
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 // with few survivors above it skips the threshold bisection.  A bound is only ever a score K documents already reached,
 // so dropping what lies strictly below it cannot change the merged top-k (ties at the bound are kept).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kTileDocs = 12288;
+constexpr int kTileDocs = 9216;
 constexpr u64 kSkipMinDf = 2048;
 constexpr int kMaxSlots = 64;      // query terms the tiled kernel takes (longer queries use the global-accumulator form)
 
@@ -432,7 +434,7 @@ struct Bm25Index {
         }
         const i64 wave_cand = lists * k;
         const i64 per_lane = (wave_cand + 1023) / 1024;
-        auto mk = merge_packed_kernel<20>;
+        auto mk = merge_packed_loop_kernel<8>;   // any size
         if (per_lane <= 16) mk = merge_packed_kernel<16>;
         if (per_lane <= 1) mk = merge_packed_kernel<1>;
         else if (per_lane <= 2) mk = merge_packed_kernel<2>;
@@ -473,7 +475,7 @@ struct Bm25Index {
         int32_t rc;
         int longest = 0;
         for (int b = 0; b < nq; ++b) longest = std::max(longest, qoff[b + 1] - qoff[b]);
-        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * 4 * k <= 20 * 64 * 16)
+        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * 4 * k <= 64 * 64 * 16)
             return search_tiled(terms, qoff, nq, k, o64p, o32p, oidp, st);
         if ((rc = reserve(k))) return rc;
         for (int q0 = 0; q0 < nq; q0 += kBatch) {

@@ -568,4 +568,60 @@ __global__ __launch_bounds__(1024) void merge_packed_kernel(const u64* __restric
     }
 }
 
+// The same merge for any number of candidates: every wave walks its sixteenth of them in rounds of 8 per lane and offers
+// them to a running sorted list (most slots of a tiled BM25 search are empty: a bound shared by the tiles of a query
+// leaves later tiles a handful of survivors, and an empty slot costs one compare).
+template <int ROUND = 8>
+__global__ __launch_bounds__(1024) void merge_packed_loop_kernel(const u64* __restrict__ ck, const i64* __restrict__ ci, i64 ncand,
+                                                                int k, i64 id_base, double* __restrict__ out64,
+                                                                float* __restrict__ out32, i64* __restrict__ out_ids)
+{
+    __shared__ u64 lists[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;
+    const u64* sk = ck + (i64)q * ncand;
+    const i64* si = ci + (i64)q * ncand;
+    {
+        const i64 per_wave = ((ncand + 15) / 16 + 63) / 64 * 64;
+        const i64 lo = (i64)wave * per_wave, hi = min(lo + per_wave, ncand);
+        WaveListPacked L;
+        L.init();
+        u64 tau = 0;
+        for (i64 base = lo; base < hi; base += ROUND * 64) {
+            u64 c[ROUND];
+            i64 cs[ROUND];
+#pragma unroll
+            for (int n = 0; n < ROUND; ++n) {   // unconditional loads (clamped), masked afterwards
+                const i64 i = min(base + n * 64 + lane, ncand - 1);
+                c[n] = sk[i];
+                cs[n] = si[i];
+            }
+#pragma unroll
+            for (int n = 0; n < ROUND; ++n) {
+                const i64 i = base + n * 64 + lane;
+                const u64 key = (i < hi && c[n] != 0) ? (c[n] | (u64)(0xFFFFFFFFu - (u32)cs[n])) : 0;
+                tau = L.offer(key, k, tau);
+            }
+        }
+        lists[wave * 64 + lane] = lane < k ? L.e : 0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        u64 c[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) c[n] = lists[n * 64 + lane];
+        WaveListPacked L;
+        wave_topk_packed<16>(c, k, L);
+        if (lane < k) {
+            const i64 o = (i64)q * k + lane;
+            const bool ok = L.e != 0;
+            const float s = ok ? packed_value(L.e) : -3.402823466e+38f;
+            if (out64) out64[o] = ok ? (double)s : -1.7976931348623157e+308;
+            if (out32) out32[o] = s;
+            out_ids[o] = ok ? (i64)packed_index(L.e) + id_base : -1;
+        }
+    }
+}
+
 }  // namespace hiprag

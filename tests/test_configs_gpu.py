@@ -2,7 +2,7 @@
 GPU parity at the BASELINE.json configurations the round-1 suite did not reach ("configs_untested"):
 
   configs[2]  1M chunks hybrid: dense flat-IP top-50 + BM25 term-at-a-time top-50 + RRF -> top-10, ranks bit-exact
-              (BM25 at 1M documents = 82 document tiles, skip tables, the shared per-query bound theta)
+              (BM25 at 1M documents = 109 document tiles, skip tables, the shared per-query bound theta)
   configs[4]  the 24-layer, H = 1024 encoder (BGE-M3 / bge-reranker-v2-m3 architecture, rag/config.py:9,25) against the
               fp32 oracle, and the embed -> hybrid -> rerank chain on one GPU with every stage checked against the oracle
               fed the GPU's OWN previous-stage output (rag/providers/hf/embeddings.py:61-88 -> rag/storage/faiss_index.py:63-91
@@ -53,7 +53,7 @@ def _zipf_postings_on_gpu(torch, dev, N, V, seed=777):
 
 def test_config2_1m_chunks_hybrid_bit_exact(gpu):
     """configs[2] at full size.  Host builder == oracle builder (offsets, doc ids, fp32 impacts bit-equal); then 24 queries:
-    20 Zipf queries + one whose six lists are all long (>= 2048 postings in EVERY full one of the 82 document tiles: skip
+    20 Zipf queries + one whose six lists are all long (>= 2048 postings in EVERY full one of the 109 document tiles: skip
     tables everywhere), one of short lists only (every tile filters whole lists), one mixing both with a duplicated
     term, one empty.  BM25 ids AND fp32 scores, dense top-50 ids, fused top-10 ids and scores: bit-exact vs the oracle."""
     import torch
@@ -67,13 +67,13 @@ def test_config2_1m_chunks_hybrid_bit_exact(gpu):
     assert np.array_equal(p.offsets, op.offsets) and np.array_equal(p.doc_ids, op.doc_ids)
     assert np.array_equal(p.impacts, op.impacts)
     df = np.diff(p.offsets.astype(np.int64))
-    tile = 12288                     # kTileDocs of csrc/bm25.hip
+    tile = 9216                      # kTileDocs of csrc/bm25.hip
     ntiles = (N + tile - 1) // tile
-    assert ntiles == 82
+    assert ntiles == 109
 
     def per_tile_min(t):
         lo, hi = int(p.offsets[t]), int(p.offsets[t + 1])
-        return np.bincount(p.doc_ids[lo:hi] // tile, minlength=ntiles)[:N // tile].min()   # the 81 full tiles
+        return np.bincount(p.doc_ids[lo:hi] // tile, minlength=ntiles)[:N // tile].min()   # the 108 full tiles
 
     cands = [t for t in range(16, 100, 3) if per_tile_min(t) >= 2048]
     assert len(cands) >= 6, cands
