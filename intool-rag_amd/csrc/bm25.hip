@@ -80,6 +80,8 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 // so dropping what lies strictly below it cannot change the merged top-k (ties at the bound are kept).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTileDocs = 9216;
+constexpr int kTileThreads = 256;   // workgroup of the tiled kernel
+constexpr int kTileWaves = kTileThreads / 64;
 constexpr u64 kSkipMinDf = 2048;
 constexpr int kMaxSlots = 64;      // query terms the tiled kernel takes (longer queries use the global-accumulator form)
 
@@ -91,7 +93,7 @@ struct TileSlot {   // posting range of one (query, term slot); skip = first ent
 // IDX32: fewer than 2^30 postings in all, so posting indices and their byte offsets fit 32 bits -- the stream's index
 // arithmetic (a third of its instructions as 64-bit adds, compares and selects) becomes single 32-bit operations.
 template <bool IDX32>
-__global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ doc_ids, const float* __restrict__ impacts,
+__global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __restrict__ doc_ids, const float* __restrict__ impacts,
                                                         const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
                                                         const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
                                                         u64* __restrict__ ck, i64* __restrict__ ci, u32* __restrict__ theta,
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
         ra[tid] = a;
         rb[tid] = b;
     }
-    for (int i = tid; i < kTileDocs / 4; i += 256) reinterpret_cast<float4*>(tacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < kTileDocs / 4; i += kTileThreads) reinterpret_cast<float4*>(tacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (dp && tid == 0) dp[1] = wall_clock64();
     // The slots form ONE stream of 2048-posting chunks: the loads of the next chunks -- of the same slot or of the next
     // ones -- are in flight while this chunk's accumulator updates run; a workgroup barrier separates slots only.
-    constexpr int U = 8;
-    constexpr u64 CH = (u64)U * 256;
+    constexpr int U = 2048 / kTileThreads;
+    constexpr u64 CH = (u64)U * kTileThreads;
     // Loads are UNCONDITIONAL (lanes past the end of a range read posting 0, the buffers never have fewer than four
     // entries) and nothing touches the loaded values before the accumulate step: a load behind a lane mask or a
     // branch is compiled into branch + load + wait, i.e. one memory round trip per posting (this loop used to spend
@@ -135,12 +137,12 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
 #pragma unroll
         for (int j = 0; j < U; ++j) {   // eight independent 1 KiB-per-instruction loads of each stream
             if (IDX32) {
-                const u32 i = (u32)i0 + (u32)j * 256u + (u32)tid;
+                const u32 i = (u32)i0 + (u32)j * (u32)kTileThreads + (u32)tid;
                 const u32 ic = i < (u32)b ? i : 0u;
                 d[j] = doc_ids[ic];
                 im[j] = impacts[ic];
             } else {
-                const u64 i = i0 + (u64)j * 256 + tid;
+                const u64 i = i0 + (u64)j * kTileThreads + tid;
                 const u64 ic = i < b ? i : 0;
                 d[j] = doc_ids[ic];
                 im[j] = impacts[ic];
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const u32 x = dR[r][j] - tlo;
-                const bool inr = IDX32 ? ((u32)pR[r] + (u32)j * 256u + (u32)tid < (u32)bR[r])
-                                       : (pR[r] + (u64)j * 256 + tid < bR[r]);
+                const bool inr = IDX32 ? ((u32)pR[r] + (u32)j * (u32)kTileThreads + (u32)tid < (u32)bR[r])
+                                       : (pR[r] + (u64)j * kTileThreads + tid < bR[r]);
                 dd[j] = (inr && x < tlen) ? x : 0xFFFFFFFFu;
                 cur[j] = tacc[dd[j] != 0xFFFFFFFFu ? dd[j] : 0u];
             }
@@ -199,11 +201,11 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     __syncthreads();
     if (dp && tid == 0) dp[2] = wall_clock64();
     // ---- tile top-K1 out of LDS: wave w filters accumulators [4096 w, 4096 (w + 1)) like select_wave_kernel<true> ----
-    constexpr int NV = kTileDocs / 1024;   // float4 per lane: a wave filters a quarter of the tile
+    constexpr int NV = kTileDocs / (kTileWaves * 256);   // float4 per lane: a wave filters its share of the tile
     float v[NV * 4];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-        const float4 x = reinterpret_cast<const float4*>(tacc)[wv * (kTileDocs / 16) + it * 64 + lane];
+        const float4 x = reinterpret_cast<const float4*>(tacc)[wv * (kTileDocs / kTileWaves / 4) + it * 64 + lane];
         v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
     }
     float m = -INFINITY;
@@ -244,17 +246,17 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
     // every lane counts the keys above its own one or two, keys are unique (score bits | document), so rank = final
     // position: ~64 ballots + ~m broadcast reads instead of 64 conditional serial inserts into a sorted wave list.
     const float thrf = best ? unord32(best) : 0.f;
-    const i64 o = (((i64)q * gridDim.y + tile) * 4 + wv) * K1;
+    const i64 o = (((i64)q * gridDim.y + tile) * kTileWaves + wv) * K1;
     if (tlen < (u32)kTileDocs) {   // last, partial tile only: accumulators past the end of the collection never count
 #pragma unroll
         for (int n = 0; n < NV * 4; ++n) {
-            const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+            const u32 local = (u32)wv * (u32)(kTileDocs / kTileWaves) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
             if (local >= tlen) v[n] = -INFINITY;
         }
     }
     // one pass: a survivor (v >= threshold; non-positive accumulators are -inf by now) is rare -- ~75 of a wave's 4096 --
     // so most of the 64 steps are one compare and one scalar branch
-    u64* comp = reinterpret_cast<u64*>(tacc + wv * (kTileDocs / 4));
+    u64* comp = reinterpret_cast<u64*>(tacc + wv * (kTileDocs / kTileWaves));
     int ms = 0;
 #pragma unroll
     for (int n = 0; n < NV * 4; ++n) {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
         if (mask) {
             if (keep) {
                 const int pos = ms + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+                const u32 local = (u32)wv * (u32)(kTileDocs / kTileWaves) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
                 if (pos < 128) comp[pos] = pack_key(v[n], tlo + local);
             }
             ms += __popcll(mask);
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void taat_tile_kernel(const u32* __restrict__ 
         u64 tau = best ? ((u64)best << 32) - 1 : 0;
 #pragma unroll
         for (int n = 0; n < NV * 4; ++n) {
-            const u32 local = (u32)wv * (u32)(kTileDocs / 4) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
+            const u32 local = (u32)wv * (u32)(kTileDocs / kTileWaves) + (u32)(n >> 2) * 256u + (u32)lane * 4u + (u32)(n & 3);
             u64 c = 0;
             if (v[n] > 0.f && local < tlen) c = pack_key(v[n], tlo + local);
             tau = L.offer(c, K1, tau);
@@ -392,7 +394,7 @@ struct Bm25Index {
                 bytes_alg += (i64)(sl.hi - sl.lo) * 8;
             }
         }
-        const i64 lists = ntiles() * 4;
+        const i64 lists = ntiles() * kTileWaves;
         unsigned long long* dbg_p = nullptr;
         if (getenv("HIPBM25_DEBUG_PHASES")) {
             if ((rc = dbg.reserve((size_t)nq * ntiles() * 64))) return rc;
@@ -415,7 +417,7 @@ struct Bm25Index {
             lds_ok = true;
         }
         auto tile_kernel = n_postings < ((i64)1 << 30) ? taat_tile_kernel<true> : taat_tile_kernel<false>;
-        hipLaunchKernelGGL(tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(256), kTileDocs * sizeof(float), st,
+        hipLaunchKernelGGL(tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(kTileThreads), kTileDocs * sizeof(float), st,
                            doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
                            max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), dbg_p);
         if (dbg_p) {
@@ -475,7 +477,7 @@ struct Bm25Index {
         int32_t rc;
         int longest = 0;
         for (int b = 0; b < nq; ++b) longest = std::max(longest, qoff[b + 1] - qoff[b]);
-        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * 4 * k <= 64 * 64 * 16)
+        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * kTileWaves * k <= 64 * 64 * 16)
             return search_tiled(terms, qoff, nq, k, o64p, o32p, oidp, st);
         if ((rc = reserve(k))) return rc;
         for (int q0 = 0; q0 < nq; q0 += kBatch) {
