@@ -268,6 +268,8 @@ def main():
     my_chunks = chunks_of_rank(n_chunks, world, rank)
     row_lo = my_chunks[0] * chunk if my_chunks else 0
     index = HipFlatIndex(DIM, "ip", device=local_rank)
+    if os.environ.get("HIPRAG_BENCH_NO_RESERVE") != "1":
+        index.reserve_rows(sum(min(chunk, n_rows - c * chunk) for c in my_chunks))   # the shard's size is known: no growth cycles
     keep_host = (world == 1 and not args.no_cpu_baseline)
     host_rows = []
     t0 = time.time()

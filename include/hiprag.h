@@ -120,6 +120,10 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
 int32_t hipidx_set_spare_cus(uint64_t h, int32_t n);
 /* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);
+/* Capacity for n_rows rows now (one allocation of each of the index's buffers; rows added later beyond it grow it by half
+ * again as usual).  A caller that knows the size of the collection -- create_faiss_index's one add of all embeddings,
+ * rag/storage/faiss_index.py:121-124, or a chunked ingest -- avoids the allocate / copy / free cycles of growth. */
+int32_t hipidx_reserve_rows(uint64_t h, int64_t n_rows);
 int32_t hipidx_reconstruct(uint64_t h, int64_t row, float* out_host); /* row as stored (tests, export) */
 int32_t hipidx_save(uint64_t h, const char* path);
 int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle);

@@ -2250,6 +2250,13 @@ int32_t hipidx_set_spare_cus(uint64_t h, int32_t n)
     return HIPRAG_OK;
 }
 
+int32_t hipidx_reserve_rows(uint64_t h, int64_t n_rows)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(n_rows >= 0, "n_rows < 0");
+    return ix->grow((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
+}
+
 int32_t hipidx_reserve_search(uint64_t h, int32_t k)
 {
     GET_INDEX(h);

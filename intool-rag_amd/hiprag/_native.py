@@ -65,6 +65,7 @@ SIGNATURES = {
     "hipidx_launch_queries": [c_uint64, i32p],
     "hipidx_set_spare_cus": [c_uint64, c_int32],
     "hipidx_reserve_search": [c_uint64, c_int32],
+    "hipidx_reserve_rows": [c_uint64, c_int64],
     "hipidx_reconstruct": [c_uint64, c_int64, c_void_p],
     "hipidx_save": [c_uint64, c_char_p],
     "hipidx_load": [c_char_p, c_int32, u64p],

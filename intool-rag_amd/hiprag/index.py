@@ -139,6 +139,10 @@ class HipFlatIndex:
     def reserve_search(self, k: int) -> None:
         nat.call("hipidx_reserve_search", self._h, int(k))
 
+    def reserve_rows(self, n_rows: int) -> None:
+        """Capacity for n_rows rows in one allocation (hipidx_reserve_rows)."""
+        nat.call("hipidx_reserve_rows", self._h, int(n_rows))
+
     # ---- misc --------------------------------------------------------------------------------------
     def reconstruct(self, row: int) -> np.ndarray:
         out = np.empty(self.d, dtype=np.float32)
