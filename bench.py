@@ -409,6 +409,18 @@ def main():
                      "avg_launch_ms": round(scan_ms, 5), "launches_timed": int(st["timed_passes"]),
                      "avg_launch_ms_gpu_clock": round(wall_ms, 5), "avg_gap_ms_between_launches": round(float(st["avg_scan_gap_ms"]), 5)},
     }
+    # calibration (outside the timed region): what THIS device, now, streams read-only with the scan's partition -- boxes
+    # of the pool and allocations inside one process differ by several percent
+    try:
+        import ctypes
+        from hiprag import _native as nat
+        gbps = ctypes.c_double()
+        nat.call("hiprag_probe_read_gbps", local_rank, 2_048_000_000, 5, ctypes.byref(gbps))
+        out["roofline"]["read_probe_GBs"] = round(gbps.value, 1)
+        out["roofline"]["frac_of_read_probe"] = round(achieved / gbps.value, 4)
+    except Exception as e:   # a diagnostic must never cost the line
+        out["roofline"]["read_probe_GBs"] = None
+        print(f"[bench] read probe failed: {e!r}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle's reference-faithful twin, bounded sample, rank 0, N=1 only ----------
     if world == 1 and not args.no_cpu_baseline:

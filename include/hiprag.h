@@ -50,6 +50,11 @@ int32_t hiprag_init(int32_t n_devices);
 int32_t hiprag_shutdown(void);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the stream they run on). */
+/* Calibration, not part of the path: GB/s this device sustains on a read-only stream with the dense scan's partition
+ * (every wave its own contiguous range of 64 KiB blocks, non-temporal 16-byte loads) over a zeroed scratch buffer of
+ * `bytes`, `reps` timed launches of four passes each.  bench.py reports it beside the scan's achieved rate. */
+int32_t hiprag_probe_read_gbps(int32_t device, int64_t bytes, int32_t reps, double* out_gbps);
+
 int32_t hiprag_event_create(uint64_t* out_event);
 int32_t hiprag_event_record(uint64_t event, void* stream);
 int32_t hiprag_event_elapsed_ms(uint64_t start, uint64_t stop, float* out_ms); /* synchronises on stop */

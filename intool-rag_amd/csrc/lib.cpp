@@ -21,6 +21,35 @@ static Registry<hipEvent_t>& events()
     return r;
 }
 
+namespace {
+// hiprag_probe_read_gbps: what this device streams through a statically partitioned read (the dense scan's access
+// pattern without its work): every wave reads its own contiguous range of 64 KiB blocks, 16 KiB in flight per wave,
+// non-temporal 16-byte loads.
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void read_probe_kernel(const probe_f4* __restrict__ x, long long nblocks, int bpw, int passes,
+                                                        float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long gw = (long long)blockIdx.x * 8 + wave;
+    probe_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < passes; ++pass) {
+        for (int i = 0; i < bpw; ++i) {
+            const long long b = gw * bpw + i;
+            if (b >= nblocks) break;
+            const probe_f4* src = x + b * 4096 + lane;   // a block = 64 KiB = 4096 x 16 B
+            for (int p = 0; p < 64; p += 16) {
+                probe_f4 r[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) r[u] = __builtin_nontemporal_load(src + (p + u) * 64);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += r[u];
+            }
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;   // never true for a zeroed buffer: keeps the loads
+}
+}  // namespace
+
 }  // namespace hiprag
 
 using namespace hiprag;
@@ -65,6 +94,45 @@ int32_t hiprag_shutdown(void)
     clear_bm25_registry();
     clear_dense_registry();
     events().clear();
+    return HIPRAG_OK;
+}
+
+int32_t hiprag_probe_read_gbps(int32_t device, int64_t bytes, int32_t reps, double* out_gbps)
+{
+    HR_REQUIRE(out_gbps && bytes >= (1 << 20) && reps > 0, "bad probe arguments");
+    HR_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HR_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const long long nblocks = bytes / 65536;
+    const long long waves = (long long)ncu * 8;
+    const int bpw = (int)((nblocks + waves - 1) / waves), passes = 4;
+    void* x = nullptr;
+    float* out = nullptr;
+    HR_CHECK_HIP(hipMalloc(&x, (size_t)nblocks * 65536));
+    hipError_t e = hipMalloc(&out, 64);
+    if (e != hipSuccess) { (void)hipFree(x); HR_CHECK_HIP(e); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    e = hipMemset(x, 0, (size_t)nblocks * 65536);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) {
+        for (int it = 0; it < 2; ++it)
+            hipLaunchKernelGGL(read_probe_kernel, dim3(ncu), dim3(512), 0, 0, (const probe_f4*)x, nblocks, bpw, passes, out);
+        (void)hipEventRecord(e0, 0);
+        for (int it = 0; it < reps; ++it)
+            hipLaunchKernelGGL(read_probe_kernel, dim3(ncu), dim3(512), 0, 0, (const probe_f4*)x, nblocks, bpw, passes, out);
+        (void)hipEventRecord(e1, 0);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    (void)hipFree(x);
+    HR_CHECK_HIP(e);
+    *out_gbps = (double)nblocks * 65536.0 * passes * reps / ((double)ms * 1e-3) / 1e9;
     return HIPRAG_OK;
 }
 

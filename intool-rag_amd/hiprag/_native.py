@@ -46,6 +46,7 @@ SIGNATURES = {
                          c_float, c_void_p, c_void_p],
     "hiprag_event_create": [u64p],
     "hiprag_event_record": [c_uint64, c_void_p],
+    "hiprag_probe_read_gbps": [c_int32, c_int64, c_int32, POINTER(c_double)],
     "hiprag_select_topk_dev": [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     "hiprag_event_elapsed_ms": [c_uint64, c_uint64, f32p],
     "hiprag_event_destroy": [c_uint64],
