@@ -261,6 +261,9 @@ def main():
         os.environ["HIPRAG_FORCE_EXCHANGE"] = "1"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the one collective of a step moves 80-160 KB per rank: four channels are plenty, and every channel is a workgroup
+        # that spins on a CU until all ranks have joined -- CUs the scan (which leaves 8 spare) would otherwise wait for
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
         if args.share_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)
