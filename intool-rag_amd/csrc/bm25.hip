@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 // lists are read whole by every tile and filtered -- 109 tiles x < 2048 postings costs less than a table lookup chain.
 // Determinism: a document occurs at most once per list, so within a slot no two threads touch the same accumulator and
 // the barrier between slots keeps every document's fp32 sum in query-term order, exactly the oracle's.
-// Selection: grid (nq, ntiles), queries fastest.  theta[q] (zeroed per launch) carries the best K-th score any finished
+// Selection: grid (nq, ntiles), queries fastest.  Two bounds per query, zeroed per launch: hist[q] (score histogram of the
+// documents emitted so far, see the kernel) and theta[q], which carries the best K-th score any finished
 // wave of query q has published, as order-preserving u32 bits; a wave whose own maximum is below it emits nothing, one
 // with few survivors above it skips the threshold bisection.  A bound is only ever a score K documents already reached,
 // so dropping what lies strictly below it cannot change the merged top-k (ties at the bound are kept).
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kTaatThreads) void taat_kernel(const u32* __restric
 constexpr int kTileDocs = 9216;
 constexpr int kTileThreads = 256;   // workgroup of the tiled kernel
 constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kHistBuckets = 2048;  // score buckets of the per-query bound histogram (+ 1 word: highest bucket used)
 constexpr u64 kSkipMinDf = 2048;
 constexpr int kMaxSlots = 64;      // query terms the tiled kernel takes (longer queries use the global-accumulator form)
 
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
                                                         const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
                                                         const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
                                                         u64* __restrict__ ck, i64* __restrict__ ci, u32* __restrict__ theta,
-                                                        unsigned long long* __restrict__ dbg)
+                                                        u32* __restrict__ hist, unsigned long long* __restrict__ dbg)
 {
     extern __shared__ float tacc[];  // kTileDocs accumulators
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
             }
         }
     };
+    float wmax = 0.f;
     int cs = 0;              // cursor: next chunk to fetch = [cpos, ..) of slot cs
     u64 cpos = ns > 0 ? ra[0] : 0;
     auto next_chunk = [&](int& slot, u64& pos, u64& bound) -> bool {
@@ -189,8 +192,13 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
                 cur[j] = tacc[dd[j] != 0xFFFFFFFFu ? dd[j] : 0u];
             }
 #pragma unroll
-            for (int j = 0; j < U; ++j)
-                if (dd[j] != 0xFFFFFFFFu) tacc[dd[j]] = cur[j] + mR[r][j];
+            for (int j = 0; j < U; ++j) {
+                if (dd[j] != 0xFFFFFFFFu) {
+                    const float nv = cur[j] + mR[r][j];
+                    tacc[dd[j]] = nv;
+                    wmax = fmaxf(wmax, nv);   // impacts are positive: the largest value ever written is the tile's best final score
+                }
+            }
             const int nr = (r + 1) % D;              // the chunk that follows in stream order (static after unrolling)
             const bool boundary = !hR[nr] || sR[nr] != sR[r];
             hR[r] = next_chunk(sR[r], pR[r], bR[r]); // re-arm this entry before the barrier: its loads fly through it
@@ -198,9 +206,54 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
             if (boundary) __syncthreads();           // slot boundary: later slots add to the same documents
         }
     }
+    __shared__ float smax[kTileWaves];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+    if (lane == 0) smax[wv] = wmax;
     __syncthreads();
     if (dp && tid == 0) dp[2] = wall_clock64();
+    float tile_top = 0.f;
+#pragma unroll
+    for (int w = 0; w < kTileWaves; ++w) tile_top = fmaxf(tile_top, smax[w]);
     // ---- tile top-K1 out of LDS: wave w filters accumulators [4096 w, 4096 (w + 1)) like select_wave_kernel<true> ----
+    // theta[q] = the best K1-th score any finished wave of this query has published (ordered-integer form, grows
+    // monotonically): a lower bound of the query's final K1-th score, so nothing below it can reach the result.  The
+    // first tiles of a query pay the full selection; later ones start from a threshold that is already almost final
+    // and keep only a handful of documents.  Which tiles profit depends on timing, the merged top-k does not.
+    u32 th = __hip_atomic_load(theta + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A second, much tighter bound: hist[q] counts the documents every finished wave of this query has emitted, by score
+    // bucket (sign-free float bits >> 20: exponent and three mantissa bits, 12.5 % wide); hist[q][kHistBuckets] is the
+    // highest bucket used.  If the buckets from b upwards hold K1 documents, K1 documents score at least b's lower edge.
+    // theta alone is the best K1-th score of ONE wave's 2304 documents -- about the 10,000th best of 1M -- and left every
+    // wave ~50 survivors to compact and rank (and often a bisection first); this bound follows the query's true K1-th
+    // score to within a bucket after the first few tiles and leaves most waves none.
+    if (hist) {
+        const u32* hq = hist + (size_t)q * (kHistBuckets + 1);
+        const u32 hm = __hip_atomic_load(hq + kHistBuckets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hm != 0) {
+            const int b = (int)hm - 63 + lane;   // lanes cover the 64 buckets up to the highest one: a factor 256 in score
+            u32 suffix = b > 0 ? __hip_atomic_load(hq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 up = (u32)__shfl_down((int)suffix, off);
+                if (lane + off < 64) suffix += up;
+            }
+            const unsigned long long okm = __ballot(suffix >= (u32)K1);
+            if (okm) {
+                const int l = 63 - __builtin_clzll(okm);
+                const u32 hb = 0x80000000u | ((u32)((int)hm - 63 + l) << 20);   // ord32 image of the bucket's lower edge
+                th = hb > th ? hb : th;
+            }
+        }
+    }
+    // the whole tile is below the bound: no pass over the accumulators at all (about 40 % of the tiles once the bound has
+    // converged -- a query's best ~100 documents leave that share of its 109 tiles without any of them)
+    if (th != 0 && (!(tile_top > 0.f) || th > ord32(tile_top))) {
+        const i64 o0 = (((i64)q * gridDim.y + tile) * kTileWaves + wv) * K1;
+        if (lane < K1) { ck[o0 + lane] = 0; ci[o0 + lane] = -1; }
+        if (dp && tid == 0) { dp[3] = wall_clock64(); dp[4] = dp[3]; }
+        return;
+    }
     constexpr int NV = kTileDocs / (kTileWaves * 256);   // float4 per lane: a wave filters its share of the tile
     float v[NV * 4];
 #pragma unroll
@@ -212,11 +265,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
 #pragma unroll
     for (int n = 0; n < NV * 4; ++n) m = fmaxf(m, v[n] > 0.f ? v[n] : -INFINITY);
     const u32 mo = m == -INFINITY ? 0u : ord32(m);
-    // theta[q] = the best K1-th score any finished wave of this query has published (ordered-integer form, grows
-    // monotonically): a lower bound of the query's final K1-th score, so nothing below it can reach the result.  The
-    // first tiles of a query pay the full selection; later ones start from a threshold that is already almost final
-    // and keep only a handful of documents.  Which tiles profit depends on timing, the merged top-k does not.
-    const u32 th = __hip_atomic_load(theta + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 best = 0;
     u32 top = mo;
 #pragma unroll
@@ -284,6 +332,15 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
         if (lane < K1 && lane >= ms) { ck[o + lane] = 0; ci[o + lane] = -1; }
         if (k0 != 0 && r0 < K1) { ck[o + r0] = k0 & 0xFFFFFFFF00000000ull; ci[o + r0] = (i64)packed_index(k0); }
         if (k1 != 0 && r1 < K1) { ck[o + r1] = k1 & 0xFFFFFFFF00000000ull; ci[o + r1] = (i64)packed_index(k1); }
+        if (hist) {
+            u32* hq = hist + (size_t)q * (kHistBuckets + 1);
+            u32 bmax = 0;
+            if (k0 != 0 && r0 < K1) { const u32 b = ((u32)(k0 >> 32) >> 20) & (kHistBuckets - 1); atomicAdd(hq + b, 1u); bmax = b; }
+            if (k1 != 0 && r1 < K1) { const u32 b = ((u32)(k1 >> 32) >> 20) & (kHistBuckets - 1); atomicAdd(hq + b, 1u); bmax = max(bmax, b); }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) bmax = max(bmax, (u32)__shfl_xor((int)bmax, off));
+            if (lane == 0 && bmax != 0) atomicMax(hq + kHistBuckets, bmax);
+        }
         // this wave holds K1 documents at or above the key of rank K1 - 1: publish the bound
         if (k0 != 0 && r0 == K1 - 1) atomicMax(theta + q, (u32)(k0 >> 32));
         if (k1 != 0 && r1 == K1 - 1) atomicMax(theta + q, (u32)(k1 >> 32));
@@ -301,6 +358,14 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
         if (lane < K1) {
             ck[o + lane] = L.e & 0xFFFFFFFF00000000ull;
             ci[o + lane] = L.e ? (i64)packed_index(L.e) : -1;
+        }
+        if (hist) {
+            u32* hq = hist + (size_t)q * (kHistBuckets + 1);
+            u32 bmax = 0;
+            if (lane < K1 && L.e != 0) { const u32 b = ((u32)(L.e >> 32) >> 20) & (kHistBuckets - 1); atomicAdd(hq + b, 1u); bmax = b; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) bmax = max(bmax, (u32)__shfl_xor((int)bmax, off));
+            if (lane == 0 && bmax != 0) atomicMax(hq + kHistBuckets, bmax);
         }
         const u64 kth = L.kth(K1);   // this wave holds K1 documents at or above it: publish the bound
         if (lane == 0 && kth != 0) atomicMax(theta + q, (u32)(kth >> 32));
@@ -345,7 +410,7 @@ struct Bm25Index {
     int device = 0;
     i64 n_docs = 0, n_terms = 0, n_postings = 0, id_base = 0;
     std::vector<uint64_t> offsets;  // host copy: planning happens on the host
-    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg, theta_dev;
+    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg, theta_dev, hist_dev;
     std::vector<i64> skip_index;         // per term: first entry of its skip table, or -1 (short lists)
     std::vector<TileSlot> plan_slots;    // host staging of the last query plan (kept alive for the async copy)
     std::vector<int> plan_nslots;
@@ -408,6 +473,14 @@ struct Bm25Index {
         HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots.data(), plan_nslots.size() * sizeof(int), hipMemcpyHostToDevice, st));
         if ((rc = theta_dev.reserve((size_t)nq * sizeof(u32)))) return rc;
         HR_CHECK_HIP(hipMemsetAsync(theta_dev.p, 0, (size_t)nq * sizeof(u32), st));
+        static const bool use_hist = [] { const char* e = getenv("HIPBM25_BOUND"); return !(e && e[0] == 't'); }();   // HIPBM25_BOUND=theta: round 1's bound only
+        u32* hist_p = nullptr;
+        if (use_hist) {
+            const size_t hbytes = (size_t)nq * (kHistBuckets + 1) * sizeof(u32);
+            if ((rc = hist_dev.reserve(hbytes))) return rc;
+            HR_CHECK_HIP(hipMemsetAsync(hist_dev.p, 0, hbytes, st));
+            hist_p = hist_dev.as<u32>();
+        }
         static bool lds_ok = false;
         if (!lds_ok) {
             HR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taat_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -419,7 +492,7 @@ struct Bm25Index {
         auto tile_kernel = n_postings < ((i64)1 << 30) ? taat_tile_kernel<true> : taat_tile_kernel<false>;
         hipLaunchKernelGGL(tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(kTileThreads), kTileDocs * sizeof(float), st,
                            doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
-                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), dbg_p);
+                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), hist_p, dbg_p);
         if (dbg_p) {
             HR_CHECK_HIP(hipStreamSynchronize(st));
             std::vector<unsigned long long> h((size_t)nq * ntiles() * 8);
