@@ -202,7 +202,8 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
  * What rag/query/retriever.py does per query batch with three calls, for hosts that bind the C-ABI directly: host
  * queries and term lists in, fused fp32 scores / ids out; the two result lists never leave the GPU.  Both handles must
  * live on the same device.  Row-sharded serving keeps using the three calls (the all-gather sits between search and
- * fusion, hiprag/sharded.py) -- ranks are global, so fusion has to follow the merge. */
+ * fusion, hiprag/sharded.py) -- ranks are global, so fusion has to follow the merge.  The BM25 leg runs on a library-owned helper stream beside the dense leg (they are independent; the
+ * dense scan is HBM-bound, BM25 is not) and RRF behind both. */
 int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
                          const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
                          float w_sparse, float* out_scores, int64_t* out_ids);

@@ -56,3 +56,30 @@ def hybrid_search(index, bm25, queries, sparse_queries, depth: int = 50, k: int 
              qoff.ctypes.data, nq, int(depth), int(k), float(c), float(w_dense), float(w_sparse), scores.ctypes.data,
              ids.ctypes.data)
     return scores, ids
+
+
+_SIDE = {}
+
+
+def hybrid_search_device(index, bm25, q_dev, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0,
+                         w_dense: float = 1.0, w_sparse: float = 1.0):
+    """Device-resident form of hybrid_search: q_dev is a float32 CUDA tensor [nq, d]; returns (fused scores float32 [nq, k],
+    ids int64 [nq, k]) as CUDA tensors ordered on the current stream.  The BM25 leg runs on a helper stream beside the
+    dense leg (hiphybrid_search does the same: the legs are independent, the dense scan is HBM-bound and BM25 is not)."""
+    import torch
+    dev = q_dev.device
+    side = _SIDE.get(dev.index)
+    if side is None:
+        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)            # whatever produced the caller's inputs is ahead of the BM25 leg too
+    with torch.cuda.stream(side):
+        sparse = bm25.search_device(sparse_queries, depth)
+        done = torch.cuda.Event()
+        done.record(side)
+    dense = index.search_device(q_dev, depth)
+    main.wait_event(done)
+    sparse[2].record_stream(main)
+    return rrf_fuse_device(dense[2], sparse[2], k, c=c, w_a=w_dense, w_b=w_sparse)

@@ -532,3 +532,28 @@ def test_bm25_tiled_and_global_accumulator_forms_agree_with_the_oracle(gpu, monk
     bad[lo], bad[lo + 1] = bad[lo + 1], bad[lo]
     with pytest.raises(HipRagError, match="ascending"):
         HipBM25(PostingsCSR(p.n_docs, p.n_terms, p.offsets, bad, p.impacts))
+
+
+def test_hybrid_search_device_overlaps_the_legs_and_equals_the_oracle(gpu):
+    """hiprag.hybrid_search_device (BM25 on a helper stream beside the dense leg) and the one-call C path
+    hiphybrid_search (same overlap inside the library): fused lists bit-exact vs the oracle, call after call."""
+    import torch
+    from hiprag import HipBM25, HipFlatIndex, hybrid_search, hybrid_search_device
+    n, d, depth, k, nq = 30000, 128, 50, 10, 70
+    x = ho.synthetic_vectors(n, d, seed=71)
+    q = ho.synthetic_queries(nq, d, seed=72)
+    p = ho.synthetic_postings(n, n_terms=1024, seed=73)
+    sq = ho.synthetic_sparse_queries(nq, n_terms=1024, terms_per_query=5, seed=74, min_rank=4)
+    ix = HipFlatIndex(d, "ip")
+    ix.add(x)
+    bm = HipBM25(_gpu_postings(p))
+    _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
+    _, bi = ho.bm25_search(p, sq, depth)
+    es, ei = ho.rrf_fuse(di, bi, k)
+    qd = torch.from_numpy(q).cuda()
+    for _ in range(4):
+        fs, fi = hybrid_search_device(ix, bm, qd, sq, depth=depth, k=k)
+        torch.cuda.synchronize()
+        assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es)
+        hs, hi = hybrid_search(ix, bm, q, sq, depth=depth, k=k)
+        assert np.array_equal(hi, ei) and np.array_equal(hs, es)

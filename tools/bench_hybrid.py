@@ -94,10 +94,10 @@ def main():
     b1 = bm25.stats()
     t_fuse, (fs, fids) = timeit(lambda: rrf_fuse_device(dids, sids, k))
 
-    def hybrid():
-        a = index.search_device(queries, depth)
-        b = bm25.search_device(sparse_q, depth)
-        return rrf_fuse_device(a[2], b[2], k)
+    from hiprag import hybrid_search_device
+
+    def hybrid():   # BM25 on a helper stream beside the dense leg (hiprag.hybrid_search_device)
+        return hybrid_search_device(index, bm25, queries, sparse_q, depth=depth, k=k)
 
     t_all, (hs, hids) = timeit(hybrid, reps=2)
 
