@@ -229,12 +229,193 @@ def run_legs(torch, args, dev, index, queries, legs):
     return out
 
 
+def run_config3(torch, dist, args, world, rank, local_rank, dev, use_dist):
+    """BASELINE configs[3]: 10M x 1024-d rows AND the BM25 postings of the same 10M documents, both sharded by the same
+    contiguous document ranges over the ranks; a step = one batch of hybrid queries through ShardedHybrid: local dense
+    top-50 + local BM25 top-50 -> ONE all-gather of both packed partial lists -> global merges -> RRF -> top-10.
+    Every rank builds only its own shard; the collection-wide BM25 constants (document frequencies, document count, average
+    length) are agreed with one all-reduce at build time, so a shard's impacts equal the unsharded ones."""
+    from collections import deque
+    from hiprag import HipBM25, HipFlatIndex, build_postings
+    from hiprag.sharded import ShardedHybrid, chunks_of_rank
+    n_rows = args.rows if args.rows is not None else 10_000_000
+    V, depth, terms_per_query = 262144, 50, 6
+    n_chunks = 32
+    chunk = (n_rows + n_chunks - 1) // n_chunks
+    my_chunks = [c for c in chunks_of_rank(n_chunks, world, rank) if c * chunk < n_rows]
+    row_lo = my_chunks[0] * chunk if my_chunks else 0
+    n_local = sum(min(chunk, n_rows - c * chunk) for c in my_chunks)
+    t0 = time.time()
+    index = HipFlatIndex(DIM, "ip", device=local_rank)
+    index.reserve_rows(n_local)
+    cdf = torch.cumsum(1.0 / torch.arange(1, V + 1, dtype=torch.float64, device=dev), 0)
+    cdf /= cdf[-1].clone()
+    docs_h, terms_h, len_h = [], [], []
+    for c in my_chunks:
+        rows = min(chunk, n_rows - c * chunk)
+        index.add_device(gen_chunk(torch, c, rows, dev))
+        i = torch.arange(c * chunk, c * chunk + rows, dtype=torch.int64, device=dev)
+        dl = 64 + (i * 2654435761) % 256
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + c)
+        u = torch.rand(int(dl.sum().item()), generator=g, device=dev, dtype=torch.float64)
+        terms_h.append(torch.clamp(torch.searchsorted(cdf, u), max=V - 1).to(torch.int32).cpu().numpy())
+        docs_h.append(torch.repeat_interleave(i - row_lo, dl).to(torch.int32).cpu().numpy())
+        len_h.append(dl.cpu().numpy())
+        del u, i, dl
+        if rank == 0:
+            print(f"[bench] config3: rank 0 generated chunk {c} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
+    doc_len = np.concatenate(len_h) if len_h else np.zeros(0, np.int64)
+    term = np.concatenate(terms_h) if terms_h else np.zeros(0, np.int32)
+    doc = np.concatenate(docs_h) if docs_h else np.zeros(0, np.int32)
+    del terms_h, docs_h, len_h
+    # collection-wide constants: df counts DOCUMENTS per term, so count unique (term, doc) pairs locally, then sum over ranks
+    pair = np.unique(term.astype(np.int64) * np.int64(max(n_local, 1)) + doc.astype(np.int64))
+    df = np.bincount(pair // max(n_local, 1), minlength=V).astype(np.int64)
+    del pair
+    tot = torch.tensor([int(doc_len.sum())], dtype=torch.int64, device=dev)
+    df_t = torch.from_numpy(df).to(dev)
+    if use_dist and world > 1:
+        dist.all_reduce(df_t)
+        dist.all_reduce(tot)
+    postings = build_postings(doc, term, n_local, V, doc_len, df_global=df_t.cpu().numpy(), n_docs_global=n_rows,
+                              avgdl_global=int(tot.item()) / n_rows)
+    del doc, term
+    bm25 = HipBM25(postings, device=local_rank)
+    n_postings = int(postings.offsets[-1])
+    hy = ShardedHybrid(index, bm25, row_lo)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    queries = torch.randn((N_QUERIES, DIM), generator=gq, device=dev, dtype=torch.float32)
+    queries /= queries.norm(dim=1, keepdim=True)
+    rng = np.random.default_rng(888)
+    w = 1.0 / np.arange(17, V + 1, dtype=np.float64)
+    cdfq = np.cumsum(w) / w.sum()
+    sq = []
+    for _ in range(N_QUERIES):
+        t = []
+        while len(t) < terms_per_query:
+            cnd = int(min(np.searchsorted(cdfq, rng.random()), len(cdfq) - 1)) + 16
+            if cnd not in t:
+                t.append(cnd)
+        sq.append(np.asarray(t, dtype=np.uint32))
+    BATCH = hy.max_pass
+    nb = N_QUERIES // BATCH
+    IN_FLIGHT = 4
+
+    def run_steps(n, first):
+        pending, last = deque(), None
+        for s_ in range(n):
+            b = (first + s_) % nb
+            pending.append(hy.search_begin(queries[b * BATCH:(b + 1) * BATCH], sq[b * BATCH:(b + 1) * BATCH], depth, TOPK))
+            if len(pending) >= IN_FLIGHT:
+                last = hy.search_end(pending.popleft())
+        while pending:
+            last = hy.search_end(pending.popleft())
+        return last
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup, 0)
+    barrier()
+    index.enable_timing(1)
+    barrier()
+    t1 = time.perf_counter()
+    last = run_steps(args.steps, args.warmup)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    st = index.stats()
+    index.enable_timing(False)
+    if use_dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    mine = (rank, int(index.ntotal), int(row_lo), int(BATCH), float(st["avg_scan_ms"]), int(st["bytes_per_pass"]),
+            int(st["fallback_queries"]), n_postings, [int(v) for v in last[1][0].tolist()])
+    seen = [mine]
+    if use_dist:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        seen = sorted(seen)
+    bad = (sum(v[1] for v in seen) != n_rows or any(v[3] != BATCH for v in seen) or [v[0] for v in seen] != list(range(world))
+           or any(v[8] != seen[0][8] for v in seen))          # every rank must hold the same fused list
+    if rank != 0:
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3 if bad else 0)
+    if bad:
+        print(f"[bench] FATAL: the ranks disagree or do not cover the collection: {seen}", file=sys.stderr)
+        sys.exit(3)
+    passes = (BATCH + index.pass_queries - 1) // index.pass_queries
+    slow = max(seen, key=lambda v: v[4])
+    bpl = slow[5] * passes
+    ach = bpl / (slow[4] * 1e-3) / 1e9 if slow[4] > 0 else 0.0
+    out = {"metric": "hybrid queries/sec, dense top-50 + BM25 top-50 + RRF -> top-10, 10M x 1024-d index + postings row-sharded",
+           "value": round(args.steps * BATCH / elapsed, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None,
+           "dtype": "bf16 x bf16 -> f32 filter scan + f64 re-score (dense), f32 impact sums (BM25), f32 RRF", "data": "synthetic",
+           "config": {"workload": (f"configs[3]: {n_rows} x 1024-d rows + BM25 postings of the same documents, row-sharded over "
+                                   f"{world} rank(s), hybrid top-{TOPK} at fusion depth {depth}"),
+                      "rows": n_rows, "dim": DIM, "k": TOPK, "depth": depth, "queries_per_step": BATCH, "passes_per_step": passes,
+                      "sharding": f"rows/{world}" if world > 1 else "none", "world": world,
+                      "exchange": (f"1 all-gather of [2,2,{BATCH},{depth}] int64 per step" if use_dist else "none"),
+                      "allgather_payload_bytes_per_rank": (4 * BATCH * depth * 8 if use_dist else 0),
+                      "backend": (args.backend if use_dist else "none"), "steps_in_flight": IN_FLIGHT,
+                      "rows_local": [v[1] for v in seen], "postings_local": [v[7] for v in seen]},
+           "ranks_seen": len(seen), "fallback_queries": sum(v[6] for v in seen), "build_s": round(build_s, 1),
+           "fused_lists_equal_on_all_ranks": True,
+           "roofline": {"bound": "hbm", "kernel": "scan_bf16_kernel (dense leg of the slowest rank)", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "bytes_per_launch": bpl, "passes_per_launch": passes, "avg_launch_ms": round(slow[4], 5)}}
+    print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the driver
+    would (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), from a parent that never
+    initialises the GPU.  Returns the children's exit code; rank 0's JSON line reaches stdout through the inherited pipe."""
+    import socket
+    import subprocess
+    if not args.share_gpu:
+        import torch                      # device_count() does not create a HIP context on this image
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"[bench] FATAL: --gpus {args.gpus} but only {have} GPU(s) are visible; one rank per GPU over RCCL needs "
+                  f"{args.gpus} (one-GPU rehearsal: --share-gpu --backend gloo)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] no launcher around --gpus {args.gpus}: starting the ranks with torch.distributed.run", file=sys.stderr)
+    return subprocess.run(cmd, env=env, cwd=REPO).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (debug only)")
+    ap.add_argument("--rows", type=int, default=None, help="override the index size (debug only; default 1M, config3: 10M)")
+    ap.add_argument("--workload", default="config1", choices=["config1", "config3"],
+                    help="config1 = BASELINE configs[1], the headline (dense top-10 on 1M rows, rows sharded over the ranks); "
+                         "config3 = BASELINE configs[3]: 10M rows + BM25 postings row-sharded over the ranks, hybrid top-10 through "
+                         "ShardedHybrid (one packed all-gather per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--legs", default="fp32,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
@@ -244,6 +425,14 @@ def main():
                     help="rehearsal only: run the multi-GPU code path (process group, all-gather per step, merge) on ONE rank, "
                          "so that a one-GPU box executes the RCCL calls of the N > 1 run")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # ---- N > 1 without a launcher: this process becomes the launcher.  It starts one fresh child per GPU through
+    # torch.distributed.run BEFORE anything here has touched the GPU (no HIP call, no torch.cuda call other than the device
+    # count, which does not create a context), relays their output (rank 0 prints the JSON line) and exits with their code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -253,6 +442,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a run that silently measures another number of GPUs than it was asked for is worse than no run
+        if rank == 0:
+            print(f"[bench] FATAL: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     use_dist = world > 1 or args.force_dist
     if args.force_dist and world == 1:
         import socket
@@ -271,17 +465,26 @@ def main():
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
         if args.share_gpu:
             local_rank = 0
+        elif local_rank >= torch.cuda.device_count():
+            print(f"[bench] FATAL: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+                  f"(RCCL needs one GPU per rank; --share-gpu --backend gloo is the one-GPU rehearsal)", file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            print(f"[bench] FATAL: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "config3":
+        return run_config3(torch, dist, args, world, rank, local_rank, dev, use_dist)
+    if args.rows is None:
+        args.rows = N_ROWS
     n_rows = args.rows
     chunk = CHUNK if n_rows == N_ROWS else max(1, n_rows // 32)
 
@@ -354,15 +557,11 @@ def main():
     elapsed = time.perf_counter() - t0
     st = index.stats()
     index.enable_timing(False)
+    scan_ms, wall_ms = float(st["avg_scan_ms"]), float(st["avg_scan_wall_ms"])
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        scan = torch.tensor([st["avg_scan_ms"], st["avg_scan_wall_ms"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(scan, op=dist.ReduceOp.MAX)
-        scan_ms, wall_ms = float(scan[0].item()), float(scan[1].item())
-    else:
-        scan_ms, wall_ms = float(st["avg_scan_ms"]), float(st["avg_scan_wall_ms"])
 
     # ---- p50 latency of single queries: (a) through the host boundary -- hipidx_search with HOST arrays in and out: H2D of
     # the query, scan, tails, D2H of the result, sync -- which is what BASELINE.md / DESIGN.md quote; (b) device-resident -----
@@ -382,20 +581,32 @@ def main():
     lat_dev = np.sort(np.asarray(lat_dev[20:]))
 
     rows_local = [int(index.ntotal)]
-    if use_dist:      # what every rank holds, as seen by the collective: lets a reader check that N ranks really took part
+    per_rank = [{"rank": 0, "rows": int(index.ntotal), "scan_ms": round(scan_ms, 5), "scan_ms_gpu_clock": round(wall_ms, 5),
+                 "bytes_per_pass": int(st["bytes_per_pass"]), "fallback_queries": int(st["fallback_queries"])}]
+    if use_dist:      # what every rank holds and measured, as seen by the collective: lets a reader check that N ranks really took part
         seen = [None] * world
-        dist.all_gather_object(seen, (rank, int(index.ntotal), int(row_lo), int(sharded.max_pass)))
-        rows_local = [v[1] for v in sorted(seen)]
-        assert sum(rows_local) == n_rows and all(v[3] == sharded.max_pass for v in seen), seen
+        dist.all_gather_object(seen, (rank, int(index.ntotal), int(row_lo), int(sharded.max_pass), scan_ms, wall_ms,
+                                      int(st["bytes_per_pass"]), int(st["fallback_queries"])))
+        seen = sorted(seen)
+        rows_local = [v[1] for v in seen]
+        if sum(rows_local) != n_rows or any(v[3] != sharded.max_pass for v in seen) or [v[0] for v in seen] != list(range(world)):
+            if rank == 0:
+                print(f"[bench] FATAL: the ranks do not cover the index: {seen}", file=sys.stderr)
+            sys.exit(3)
+        per_rank = [{"rank": v[0], "rows": v[1], "scan_ms": round(v[4], 5), "scan_ms_gpu_clock": round(v[5], 5),
+                     "bytes_per_pass": v[6], "fallback_queries": v[7]} for v in seen]
     if rank != 0:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
+    # N > 1: the roofline line is the SLOWEST rank's scan against the bytes that rank streams (the step ends with it)
+    slow = max(per_rank, key=lambda r: r["scan_ms"])
+    scan_ms, wall_ms = slow["scan_ms"], slow["scan_ms_gpu_clock"]
 
     qps = args.steps * BATCH / elapsed
     # local rows * d_pad * 2 per pass (the bf16 filter copy), PASSES passes per launch: what ONE scan launch streams
-    bytes_per_launch = int(st["bytes_per_pass"]) * PASSES
+    bytes_per_launch = int(slow["bytes_per_pass"]) * PASSES
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {
         "metric": "queries/sec, exact top-10 inner-product search, 1M x 1024-d fp32 index",
@@ -423,7 +634,10 @@ def main():
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),
         "latency_path": "hipidx_search: host query in, host results out (H2D + scan + tails + D2H + sync) on the local shard",
-        "fallback_queries": int(st["fallback_queries"]),
+        "fallback_queries": sum(r["fallback_queries"] for r in per_rank),
+        "ranks_seen": len(per_rank),
+        "per_rank": per_rank,
+        "scan_ms_min_max": [min(r["scan_ms"] for r in per_rank), max(r["scan_ms"] for r in per_rank)],
         "build_s": round(build_s, 2),
         "roofline": {"bound": "hbm", "kernel": "scan_bf16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -46,8 +46,14 @@ class PostingsCSR:
 
 
 def build_postings(doc_of_tok: np.ndarray, term_of_tok: np.ndarray, n_docs: int, n_terms: int,
-                   doc_len: Optional[np.ndarray] = None, k1: float = K1, b: float = B) -> PostingsCSR:
-    """Token stream -> CSR postings (tf = multiplicity) with precomputed fp32 impacts."""
+                   doc_len: Optional[np.ndarray] = None, k1: float = K1, b: float = B, *,
+                   df_global: Optional[np.ndarray] = None, n_docs_global: Optional[int] = None,
+                   avgdl_global: Optional[float] = None) -> PostingsCSR:
+    """Token stream -> CSR postings (tf = multiplicity) with precomputed fp32 impacts.
+
+    A document-range SHARD built on its own (one rank of a row-sharded collection) passes the collection-wide document
+    frequencies, document count and average length (`df_global`, `n_docs_global`, `avgdl_global`): idf and the length
+    normalisation are global constants of BM25, so the shard's impacts then equal those of the unsharded build."""
     doc_of_tok = np.asarray(doc_of_tok, dtype=np.int64)
     term_of_tok = np.asarray(term_of_tok, dtype=np.int64)
     if doc_len is None:
@@ -68,8 +74,10 @@ def build_postings(doc_of_tok: np.ndarray, term_of_tok: np.ndarray, n_docs: int,
     df = np.bincount(term, minlength=n_terms).astype(np.float64)
     offsets = np.zeros(n_terms + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(df).astype(np.uint64)
-    avgdl = doc_len.sum() / n_docs if n_docs else 1.0
-    idf = np.log(1.0 + (n_docs - df + 0.5) / (df + 0.5))
+    avgdl = float(avgdl_global) if avgdl_global is not None else (doc_len.sum() / n_docs if n_docs else 1.0)
+    n_all = float(n_docs_global) if n_docs_global is not None else float(n_docs)
+    df_all = np.asarray(df_global, dtype=np.float64) if df_global is not None else df
+    idf = np.log(1.0 + (n_all - df_all + 0.5) / (df_all + 0.5))
     norm = k1 * (1.0 - b + b * doc_len[doc] / avgdl)
     impacts = (idf[term] * tf * (k1 + 1.0) / (tf + norm)).astype(np.float32)
     return PostingsCSR(n_docs, n_terms, offsets, doc, impacts)

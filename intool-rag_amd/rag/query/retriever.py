@@ -44,9 +44,28 @@ class PageRanking:
     score: float
     chunks: List[RetrievedChunk]
     metadata: Dict[str, Any]
-    # Prompt / citation formatting (the reference's get_context_text / to_citation, page_retriever.py:44-75) is string
-    # assembly after the hot path and out of scope: callers that need it import the reference's own
-    # PageRanking -- INTEGRATION.md shows the one-line swap; the fields above are all it reads.
+
+    # The two formatters the reference's response stage calls on every selected page (page_response.py:73 and :163);
+    # their OUTPUT is pinned by tests/golden (page_formatting, produced by running the reference's own methods).
+    _HEADING = (("chapter", "Chapter {}"), ("section", "Section {}"), ("title", "{}"))
+    _CITED = (("chapter", "chapter"), ("section", "section"), ("subsection", "subsection"), ("title", "title"),
+              ("source_file", "source_filename"))
+
+    def get_context_text(self) -> str:
+        """Prompt context of this page (same text as page_retriever.py:43-63): an optional `[Chapter c | Section s | title]`
+        heading built from the truthy metadata fields, then the chunk texts, blank-line separated, outer whitespace stripped."""
+        heading = " | ".join(fmt.format(self.metadata[key]) for key, fmt in self._HEADING if self.metadata.get(key))
+        blocks = [f"[{heading}]"] if heading else []
+        blocks.extend(chunk.text for chunk in self.chunks)
+        return "\n\n".join(blocks).strip()
+
+    def to_citation(self) -> Dict[str, Any]:
+        """Citation record of this page (same keys and rounding as page_retriever.py:65-75)."""
+        cite: Dict[str, Any] = {"page": self.page}
+        for out_key, meta_key in self._CITED:
+            cite[out_key] = self.metadata.get(meta_key)
+        cite["relevance_score"] = round(self.score, 3)
+        return cite
 
 
 def group_chunks_by_page(chunks: List[RetrievedChunk]) -> Dict[int, List[RetrievedChunk]]:

@@ -7,6 +7,7 @@ Generates tests/golden/reference_wrapper_golden.json by RUNNING THE REFERENCE'S 
   2. search_faiss_by_vector            rag/storage/faiss_index.py:137-199 (first-index pick, chunk enrichment,
                                                                            the -1 -> LAST chunk quirk)
   3. group/rank/select pages           rag/query/page_retriever.py:145-236
+  3b. PageRanking text / citation      rag/query/page_retriever.py:43-75
   4. FileStorageManager JSON schemas   rag/storage/file_storage.py:87-166,194-252
 
 Run (in the build container only; /root/reference does not exist on the GPU box):
@@ -159,6 +160,23 @@ specs.append((rand_spec, 5))
 for spec, mp in specs:
     page_cases.append({"chunks": [[s, p] for s, p in spec], "max_pages": mp, "expected": run_pages(spec, mp)})
 golden["page_ranking"] = page_cases
+
+# ---- 3b. PageRanking.get_context_text / to_citation (page_retriever.py:43-75; consumed by page_response.py:73,163) ----
+fmt_cases = []
+fmt_specs = [
+    ({"chapter": "3", "section": "3.2", "subsection": "3.2.1", "title": "Cooling loop", "source_filename": "manual.pdf"},
+     ["first chunk", "second chunk with trailing space ", ""], 4, 0.81249),
+    ({"title": "Only a title"}, ["alone"], 1, 1.15),
+    ({"chapter": None, "section": "", "title": None, "source_filename": None}, ["  padded text\n", "x"], 9, 0.0004),
+    ({"chapter": 7, "section": 0, "title": "Zero section is falsy"}, [], 2, 0.5555),
+    ({}, ["no metadata at all", "two\n\nparagraphs"], 12, 0.33333333),
+]
+for meta, texts, page, score in fmt_specs:
+    chunks_ = [R(chunk_id=f"c{i}", text=t, score=score, page=page, metadata=meta) for i, t in enumerate(texts)]
+    pg = pr.PageRanking(page=page, score=score, chunks=chunks_, metadata=meta)
+    fmt_cases.append({"metadata": meta, "texts": texts, "page": page, "score": score,
+                      "context_text": pg.get_context_text(), "citation": pg.to_citation()})
+golden["page_formatting"] = fmt_cases
 
 out_path = os.path.join(HERE, "reference_wrapper_golden.json")
 with open(out_path, "w") as f:

@@ -20,6 +20,17 @@ def test_page_grouping_ranking_selection_match_reference():
         assert got == case["expected"]
 
 
+def test_page_context_text_and_citation_match_the_reference_output():
+    """What the reference's response stage calls on every selected page (rag/query/page_response.py:73,163): the overlay's
+    PageRanking must format exactly like the reference's (golden produced by running the reference's own methods)."""
+    from rag.query.retriever import PageRanking, RetrievedChunk
+    for case in GOLD["page_formatting"]:
+        chunks = [RetrievedChunk(f"c{i}", t, case["score"], case["page"], case["metadata"]) for i, t in enumerate(case["texts"])]
+        pg = PageRanking(page=case["page"], score=case["score"], chunks=chunks, metadata=case["metadata"])
+        assert pg.get_context_text() == case["context_text"]
+        assert pg.to_citation() == case["citation"] and list(pg.to_citation()) == list(case["citation"])
+
+
 def test_enrich_matches_reference_including_minus_one_quirk():
     from rag.storage.hip_index import enrich
     from oracle import hybrid_oracle as ho

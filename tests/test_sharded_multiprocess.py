@@ -224,6 +224,50 @@ def test_bench_rehearsal_two_ranks_under_torch_distributed_run(gpu):
     assert d["value"] > 0 and d["fallback_queries"] == 0 and "legs" not in d and "cpu_baseline" not in d
 
 
+def _bench_line(args, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=REPO)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around_it(gpu):
+    """`python bench.py --gpus 2` as a plain command (what the driver ran at N = 1 in round 2): the parent starts the two
+    ranks itself before touching the GPU and relays rank 0's line.  Rehearsal form: both ranks share cuda:0 over gloo."""
+    r, d = _bench_line(["--gpus", "2", "--steps", "4", "--warmup", "2", "--rows", "128000", "--backend", "gloo", "--share-gpu"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["rows_local"] == [64000, 64000]
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["scan_ms"] > 0 for p in d["per_rank"])
+    assert d["value"] > 0 and d["fallback_queries"] == 0 and "legs" not in d
+
+
+@pytest.mark.gpu
+def test_bench_two_rccl_ranks_on_a_one_gpu_box_fail_loudly(gpu):
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    r, d = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "128000"])
+    assert r.returncode != 0 and d is None and "FATAL" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_config3_workload_two_ranks_rehearsal(gpu):
+    """--workload config3 (rows AND postings sharded by the same document ranges, hybrid top-10 through ShardedHybrid) at a
+    rehearsal size: two ranks sharing cuda:0 over gloo, started by bench.py itself; every rank must end with the same list."""
+    r, d = _bench_line(["--gpus", "2", "--workload", "config3", "--rows", "64000", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--share-gpu"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["rows_local"] == [32000, 32000]
+    assert d["fused_lists_equal_on_all_ranks"] and d["value"] > 0 and d["config"]["allgather_payload_bytes_per_rank"] > 0
+    assert all(p > 0 for p in d["config"]["postings_local"])
+
+
 @pytest.mark.gpu
 def test_bench_single_rank_over_rccl_runs_the_exchange_path(gpu):
     """The calls of the N > 1 run that a one-GPU box CAN execute on RCCL itself: bench.py --force-dist initialises the
