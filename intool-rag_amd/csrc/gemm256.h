@@ -260,14 +260,16 @@ __global__ __launch_bounds__(G2_THREADS) void gemm256_kernel(GemmArgs g, int nbm
             };
             load_resid(0);
             load_resid(1);
-            constexpr int kStores = EPI == EPI_RESID16 ? 4 : 8;      // vector-memory stores per row group j
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // wait for the residual of group j: younger than it are the loads of group j+1 (4, if any) and the stores
-                // of group j-1 (if any); the bias loads are older than everything
-                if (j == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rq[0][0][0]), "+v"(rq[0][0][1]), "+v"(rq[0][1][0]), "+v"(rq[0][1][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]) :: "memory");
-                else if (j == 3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rq[1][0][0]), "+v"(rq[1][0][1]), "+v"(rq[1][1][0]), "+v"(rq[1][1][1]) : "i"(kStores) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rq[j & 1][0][0]), "+v"(rq[j & 1][0][1]), "+v"(rq[j & 1][1][0]), "+v"(rq[j & 1][1][1]) : "i"(kStores + 4) : "memory");
+                // Wait for the residual of group j.  Younger than it in the queue are the four loads of group j+1 (if any) and
+                // the stores of group j-1 (if any); the bias loads are older than everything.  Only the younger LOADS are
+                // allowed for in the count: loads return in order among themselves, but a store's acknowledgement may overtake an
+                // older load, so a count that also allowed for the stores could be met with a residual load still in flight.
+                // With vmcnt(4): were a load of group j outstanding, the four of group j+1 behind it would be too -- five.
+                if (j == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[1][0][0]), "+v"(rq[1][0][1]), "+v"(rq[1][1][0]), "+v"(rq[1][1][1]) :: "memory");
+                else if (j == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rq[0][0][0]), "+v"(rq[0][0][1]), "+v"(rq[0][1][0]), "+v"(rq[0][1][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" : "+v"(rq[j & 1][0][0]), "+v"(rq[j & 1][0][1]), "+v"(rq[j & 1][1][0]), "+v"(rq[j & 1][1][1]) :: "memory");
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll

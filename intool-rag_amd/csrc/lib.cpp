@@ -1,6 +1,8 @@
 // lib.cpp -- library-level entry points of libhiprag.so: error state, device queries, HIP-event timing.
 #include "common.h"
 
+#include <vector>
+
 namespace hiprag {
 
 static thread_local std::string g_last_error;
@@ -20,6 +22,68 @@ static Registry<hipEvent_t>& events()
     static Registry<hipEvent_t> r;
     return r;
 }
+
+// Helper streams of hiphybrid_search (the BM25 leg runs beside the dense leg): owned by the library, not by the calling
+// thread -- a pool per process, entries tagged with their device, handed out under a mutex and destroyed by hiprag_shutdown.
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    int dev = -1;
+};
+class SidePool {
+public:
+    int32_t acquire(int dev, SideStream& out)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].dev == dev) { out = free_[i]; free_.erase(free_.begin() + (long)i); return HIPRAG_OK; }
+        }
+        SideStream s;
+        s.dev = dev;
+        HR_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        hipError_t e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e != hipSuccess) { (void)hipStreamDestroy(s.st); HR_CHECK_HIP(e); }
+        out = s;
+        return HIPRAG_OK;
+    }
+    void release(const SideStream& s)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.push_back(s);
+    }
+    void clear()   // hiprag_shutdown (every device has been synchronised): leases still out are destroyed by their holders' release -> here next time
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (const SideStream& s : free_) {
+            if (hipSetDevice(s.dev) != hipSuccess) continue;
+            (void)hipEventDestroy(s.done);
+            (void)hipStreamDestroy(s.st);
+        }
+        free_.clear();
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<SideStream> free_;
+};
+static SidePool& side_pool()
+{
+    static SidePool p;
+    return p;
+}
+// One lease per hiphybrid_search call.  While `busy` the helper stream may still write into buffers the call's frame owns:
+// every way out of the frame (error returns included) first waits for it, then hands the stream back.
+struct SideLease {
+    SideStream s;
+    bool held = false, busy = false;
+    ~SideLease()
+    {
+        if (!held) return;
+        if (busy) (void)hipStreamSynchronize(s.st);
+        side_pool().release(s);
+    }
+};
 
 namespace {
 // hiprag_probe_read_gbps: what this device streams through a statically partitioned read (the dense scan's access
@@ -94,6 +158,7 @@ int32_t hiprag_shutdown(void)
     clear_bm25_registry();
     clear_dense_registry();
     events().clear();
+    side_pool().clear();
     return HIPRAG_OK;
 }
 
@@ -159,29 +224,22 @@ int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host,
     // The two legs are independent and use different parts of the chip -- the dense scan is HBM-bound, BM25 waits on LDS
     // round trips and barriers -- so BM25 runs on a second stream beside the dense leg (its workgroups fill the gaps
     // around the scan's tail kernels): 123-127 k -> 130-131 k hybrid queries/s at 1M chunks, same results.
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t side_done = nullptr;
-    static thread_local int side_dev = -1;
     int cur_dev = 0;
     HR_CHECK_HIP(hipGetDevice(&cur_dev));
-    if (side_dev != cur_dev) {   // one helper stream per (thread, device): created on first use, lives as long as the thread
-        if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(side_done); side = nullptr; side_done = nullptr; }
-        HR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        HR_CHECK_HIP(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
-        side_dev = cur_dev;
-    }
+    SideLease lease;   // declared AFTER the DevBufs: destroyed (= helper stream drained) before they are freed
+    if ((rc = side_pool().acquire(cur_dev, lease.s))) return rc;
+    lease.held = true;
+    lease.busy = true;   // from the first BM25 launch until the main stream has been made to wait for the leg and has drained
     if ((rc = hipbm25_search_dev(bm25_h, term_ids_host, q_offsets_host, nq, depth, s64b.as<double>(), nullptr,
-                                 idb.as<int64_t>(), side))) return rc;
-    HR_CHECK_HIP(hipEventRecord(side_done, side));
-    if ((rc = hipidx_search_dev(dense_h, q.as<float>(), nq, depth, s64a.as<double>(), nullptr, ida.as<int64_t>(), nullptr))) {
-        (void)hipStreamSynchronize(side);   // the BM25 leg still writes into buffers this frame owns
-        return rc;
-    }
-    HR_CHECK_HIP(hipStreamWaitEvent(nullptr, side_done, 0));
+                                 idb.as<int64_t>(), lease.s.st))) return rc;
+    HR_CHECK_HIP(hipEventRecord(lease.s.done, lease.s.st));
+    if ((rc = hipidx_search_dev(dense_h, q.as<float>(), nq, depth, s64a.as<double>(), nullptr, ida.as<int64_t>(), nullptr))) return rc;
+    HR_CHECK_HIP(hipStreamWaitEvent(nullptr, lease.s.done, 0));
     if ((rc = hiprrf_fuse_dev(ida.as<int64_t>(), idb.as<int64_t>(), nq, depth, depth, k, c, w_dense, w_sparse,
                               os.as<float>(), oi.as<int64_t>(), nullptr))) return rc;
     HR_CHECK_HIP(hipMemcpy(out_scores, os.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     HR_CHECK_HIP(hipMemcpy(out_ids, oi.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    lease.busy = false;   // the blocking copies above ran behind the fusion, which waited for the BM25 leg
     return HIPRAG_OK;
 }
 

@@ -168,6 +168,28 @@ def test_linear_layers_both_tiled_kernels_against_fp32_reference(gpu, epi, N, K)
         assert all(torch.equal(x, y) for x, y in zip(outs[1], outs[2]))
 
 
+def test_residual_epilogues_of_the_256_tile_kernel_repeat_bit_exact(gpu):
+    """The bias + residual epilogues of gemm256 read the residual through hand-counted `s_waitcnt vmcnt` (a count
+    that also allowed for younger stores could pass with a residual load in flight -- a timing-dependent wrong row).  Many
+    tiles per workgroup (16384 rows), thirty launches each: the fp32 form must equal the 128-tile kernel's output bit for bit
+    every time, and the bf16 form its one rounding."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    M = 16384
+    for N, K in ((1024, 1024), (1024, 4096)):
+        a = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+        w = (torch.randn((N, K), generator=g, device=dev) * 0.03).to(torch.bfloat16)
+        bias = torch.randn((N,), generator=g, device=dev) * 0.1
+        resid = torch.randn((M, N), generator=g, device=dev).to(torch.bfloat16)
+        ref32 = _linear(2, 1, a, w, bias, resid)[0]
+        ref16 = ref32.to(torch.bfloat16)
+        for _ in range(30):
+            assert torch.equal(_linear(2, 2, a, w, bias, resid)[0], ref32)
+            assert torch.equal(_linear(3, 2, a, w, bias, resid)[0], ref16)
+
+
 def test_big_batch_path_with_padded_row_tiles_and_masks(gpu, monkeypatch):
     """261 x 64-token rows = 16704 token rows: enough for the persistent 256-tile GEMMs (>= 16 k rows), and NOT a multiple of
     256, so the last row tile is padding -- the QKV epilogue has to mask its scatter, the pad rows must never reach a real
