@@ -94,31 +94,32 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
  * float (may be NULL), out_ids_dev [nq,k] int64. */
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* Queries one scan pass serves.  HIPRAG_SCAN_MODE picks the scan's operands:
- *   bf16 (default)  64 queries; the scan streams a bf16 FILTER COPY of the rows (2 B per element, kept beside the fp32
- *                   rows: 6 B per element of HBM in all) against bf16 query tiles
- *   q64             64 queries; streams the fp32 rows, split on the fly into bf16 hi + lo, against hi-only query tiles
- *   split           32 queries; hi + lo on both sides
- *   f32             32 queries; exact fp32 MFMA (verification)
- * All modes return the same exact results -- every candidate is re-scored in fp64 from the fp32 rows and a certificate
- * (or, where it fails, a second finish round / the exhaustive path) proves nothing was missed; they differ in how many
- * bytes a pass streams, how wide the certificate's error bound is and how many rows get re-scored. */
+/* Queries one scan pass serves: 64.  HIPRAG_SCAN_MODE picks the scan's operands:
+ *   bf16 (default)  the scan streams a bf16 FILTER COPY of the rows (2 B per element, kept beside the fp32 rows: 6 B per
+ *                   element of HBM in all) against bf16 query tiles
+ *   q64             streams the fp32 rows themselves, split on the fly into bf16 hi + lo, against bf16 query tiles (N*d*4
+ *                   bytes per pass: the accounting of SURVEY 8(d)); no extra memory is read
+ * Both return the same exact results -- the scan only nominates candidate groups (a per-query candidate list, filtered
+ * inside the scan against a bound it maintains itself); every candidate the finish needs is re-scored in fp64 from the fp32
+ * rows and a certificate (or, where it fails, the exhaustive path) proves nothing was missed.  The modes differ in how many
+ * bytes a pass streams and how wide the certificate's error bound is.  Any other value is rejected by hipidx_create. */
 int32_t hipidx_pass_queries(uint64_t h, int32_t* out_n);
 /* Queries one scan LAUNCH takes (a multiple of the pass size): the scan kernel runs launch/pass passes back to back
  * inside one launch -- each pass streams the index once for its own query tile -- so that no kernel boundary (45-60 us
  * of idle GPU) separates them.  Sized by the index so that a launch lasts about 2.6 ms: in the default mode 8 passes
  * (512 queries) at 1M x 1024, 16 (the cap, 1024 queries) from half that down; it changes when rows are added.
- * HIPRAG_LAUNCH_QUERIES fixes it.  The exact-fp32 mode runs one pass per launch. */
+ * HIPRAG_LAUNCH_QUERIES fixes it. */
 int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
 /* Two-phase form of one launch (nq <= hipidx_launch_queries) for callers that pipeline: begin = index scan into
- * workspace `slot` (0..7, allocated on first use); finish = group selection, fp64 re-score, top-k, certificate /
- * fallback out of that slot.  begin(slot s) of a later call must be ordered after finish(slot s) of the call that
+ * workspace `slot` (0..7, allocated on first use); finish = two kernels out of that slot (candidate ranking + fp64 re-score
+ * + top-k + certificate in one; the exhaustive path for flagged queries).  k <= 128 takes this path; deeper k (to 1000) is
+ * answered by the exhaustive path alone.  begin(slot s) of a later call must be ordered after finish(slot s) of the call that
  * used it (stream order or an event); the two phases may run on different streams if finish waits for begin.
  * search_dev == begin + finish on slot 0, repeated for every hipidx_launch_queries queries. */
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);
 int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* Leave n CUs out of the scan grid (default 0, or HIPRAG_SCAN_SPARE_CUS): the 64-query scan fills the register file of
+/* Leave n CUs out of the scan grid (default 0): the 64-query scan fills the register file of
  * every CU it runs on, so kernels of OTHER streams -- the tails of earlier launches, and at N > 1 the RCCL all-gather,
  * whose ranks spin until every peer has joined -- otherwise only run between scans.  Alone on a GPU that costs nothing
  * (0 spare CUs is 2-3 % faster than 8 at 1M rows); row-sharded serving sets 8.  Synchronises the device. */
@@ -136,28 +137,22 @@ int32_t hipidx_load(const char* path, int32_t device, uint64_t* out_handle);
 typedef struct hipidx_stats {
     int64_t passes;            /* scan passes so far (one per <= pass_queries queries; several per launch) */
     int64_t queries;           /* queries answered */
-    int64_t fallback_queries;  /* queries that took the exhaustive path (certificate failed and round B overflowed) */
+    int64_t fallback_queries;  /* queries that took the exhaustive path (certificate failed: massive ties, overflowing lists) */
     int64_t bytes_per_pass;    /* bytes of index the scan kernel reads per pass (algorithmic) */
     int64_t timed_passes;      /* scan LAUNCHES averaged into avg_scan_ms (at most the last 512) */
     float avg_scan_ms;         /* mean HIP-event duration of the scan kernel since timing was enabled, else -1 */
     float avg_scan_wall_ms;    /* same launches on the GPU wall clock, stamped inside the kernel: first wave in -> last wave out */
     float avg_scan_gap_ms;     /* mean idle time between consecutive timed scans (last wave out -> next first wave in) */
     int64_t launches;          /* scan kernel launches so far (each runs 1..launch_queries/pass_queries passes back to back) */
-    int64_t roundb_queries;    /* queries whose first certificate failed and that the second finish round settled (cheap) */
+    int64_t roundb_queries;    /* queries whose re-scored prefix the finish had to extend once (more groups within eps of the k-th score) */
+    int64_t list_entries;      /* candidate-list entries the scans wrote, summed over all queries answered by the finish */
+    int64_t ranked_entries;    /* of those, entries at or above the final bound (what the finish ranks), summed */
+    int64_t rescored_groups;   /* 16-row groups whose tagged quad was re-scored in fp64, summed */
 } hipidx_stats;
 int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
 /* on = n > 0: HIP events (on the launch stream) around every n-th scan launch, in-kernel wall-clock stamps on every launch;
  * 0 = off.  Two event records cost ~20 us of dispatch bubble between chained launches, hence the sampling.  get_stats syncs. */
 int32_t hipidx_enable_timing(uint64_t h, int32_t on);
-
-/* Exact top-k (k <= 64) of each of n_rows float arrays of n values (row r at vals + r * row_stride; 16-byte aligned, stride
- * a multiple of 4) under the library's canonical order: larger value first, then LOWER index; -inf entries are "absent".
- * out_vals / out_idx [n_rows, k], exhausted ranks -inf / -1.  This is the selector the dense finish runs over a query's
- * group maxima (one 1024-thread workgroup per array, one threshold pass: csrc/topk_device.h select_threshold_topk),
- * exported so that its edge cases can be tested directly.  The reference has no counterpart (FAISS's heap inside
- * IndexFlat::search, rag/storage/faiss_index.py:137). */
-int32_t hiprag_select_topk_dev(const float* vals_dev, int64_t row_stride, int64_t n, int32_t n_rows, int32_t k,
-                               float* out_vals_dev, int64_t* out_idx_dev, void* stream);
 
 /* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
  * in_scores64 / in_ids: n_parts blocks of [nq, k_in] (device), block p starting part_stride ELEMENTS after block

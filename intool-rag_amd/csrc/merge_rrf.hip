@@ -162,42 +162,12 @@ __global__ __launch_bounds__(64) void rrf_kernel(const i64* __restrict__ ids_a, 
     });
 }
 
-// hiprag_select_topk_dev: select_threshold_topk on plain arrays (one workgroup per row of `vals`)
-__global__ __launch_bounds__(1024) void select_rows_kernel(const float* __restrict__ vals, i64 stride, i64 n, int k,
-                                                          float* __restrict__ out_vals, i64* __restrict__ out_idx)
-{
-    __shared__ SelectScratch S;
-    __shared__ u64 out[64];
-    const int q = blockIdx.x;
-    select_threshold_topk(vals + (i64)q * stride, n, k, S, out);
-    __syncthreads();
-    if ((int)threadIdx.x < k) {
-        const u64 e = out[threadIdx.x];
-        out_vals[(i64)q * k + threadIdx.x] = e ? packed_value(e) : -INFINITY;
-        out_idx[(i64)q * k + threadIdx.x] = e ? (i64)packed_index(e) : -1;
-    }
-}
-
 }  // namespace
 }  // namespace hiprag
 
 using namespace hiprag;
 
 extern "C" {
-
-int32_t hiprag_select_topk_dev(const float* vals_dev, int64_t row_stride, int64_t n, int32_t n_rows, int32_t k,
-                               float* out_vals_dev, int64_t* out_idx_dev, void* stream)
-{
-    HR_REQUIRE(n >= 1 && n < (int64_t)1 << 32 && n_rows >= 0 && k >= 1 && k <= 64, "bad select shape (1 <= k <= 64, n < 2^32)");
-    HR_REQUIRE(row_stride >= n && row_stride % 4 == 0, "row_stride must be >= n and a multiple of 4 floats");
-    if (n_rows == 0) return HIPRAG_OK;
-    HR_REQUIRE(vals_dev && out_vals_dev && out_idx_dev, "null device pointer");
-    HR_REQUIRE(((uintptr_t)vals_dev & 15) == 0, "vals must be 16-byte aligned");
-    hipLaunchKernelGGL(select_rows_kernel, dim3(n_rows), dim3(1024), 0, (hipStream_t)stream, vals_dev, (i64)row_stride, (i64)n, k,
-                       out_vals_dev, (i64*)out_idx_dev);
-    HR_CHECK_HIP(hipGetLastError());
-    return HIPRAG_OK;
-}
 
 int32_t hiprag_merge_topk_dev(const double* in_scores64_dev, const int64_t* in_ids_dev, int32_t n_parts, int32_t nq,
                               int32_t k_in, int32_t k_out, int64_t part_stride, int32_t metric,

@@ -327,10 +327,8 @@ __device__ __forceinline__ u32 wave_bisect_threshold(const float (&v)[N], u32 lo
 constexpr int kSelPerWave = 4096;
 template <bool POSITIVE_ONLY>
 __global__ __launch_bounds__(256) void select_wave_kernel(const float* __restrict__ vals, i64 stride, i64 n_total, int K1,
-                                                         u64* __restrict__ ck, i64* __restrict__ ci,
-                                                         unsigned long long* dbg_stamp = nullptr)
+                                                         u64* __restrict__ ck, i64* __restrict__ ci)
 {
-    if (dbg_stamp && threadIdx.x == 0) atomicMin(dbg_stamp, (unsigned long long)wall_clock64());
     constexpr int NV = kSelPerWave / 256;  // float4 loads per lane
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.y;
@@ -391,128 +389,6 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const float* __restric
         const i64 o = ((i64)q * nwaves + wave) * K1 + lane;
         ck[o] = L.e & 0xFFFFFFFF00000000ull;
         ci[o] = L.e ? (i64)packed_index(L.e) : -1;
-    }
-}
-
-// Whole-array selector by threshold, K1 <= 64, for one 16-wave workgroup (1024 threads) per float array of any length.
-// select_wave_kernel builds a complete sorted top-K1 in every wave of 4096 values (a bisection and K1 serial insertions
-// per wave: ~4000 instructions, sixteen times per query at 65536 values, and a merge kernel after it); here the array is
-// read once and filtered by ONE threshold:
-//   1. thread t streams elements {4 (1024 i + t) + 0..3} and keeps only the packed key of its best one;
-//   2. wave 0 takes the exact K1-th largest of the 1024 thread maxima, tau.  K1 distinct threads hold a key >= tau, so
-//      the array's K1-th largest key is >= tau; only threads holding two or more of the winners add to the count above
-//      K1 (K1^2 / 2048 more candidates on average);
-//   3. the ~K1 threads whose maximum reaches tau read their elements again (cache hits) and append keys >= tau to an
-//      LDS list; every other thread is done -- nothing is kept in registers between the passes;
-//   4. the list (K1 <= count <= kSelCap) is ranked by counting -> out[0..K1) sorted, zeros behind.
-// Keys carry the index, so they are distinct; a count above kSelCap (a thread's strided set holding very many of the
-// winners: constant arrays and the like) is cut by bisecting tau upwards on the 64-bit keys, a few microseconds per step
-// that only degenerate inputs pay.  n_total >= 1; `src` 16-byte aligned; out = 64 entries in LDS or global memory.
-constexpr int kSelCap = 256;
-struct SelectScratch {
-    u64 tmax[1024];
-    u64 cand[kSelCap];
-    u64 tau;
-    int cnt;
-};
-
-// visits thread `tid`'s elements in ascending index order: f(value, index)
-template <class F>
-__device__ __forceinline__ void select_visit(const float* __restrict__ src, i64 n_total, int tid, F&& f)
-{
-    constexpr int U = 8;
-    const i64 n4 = n_total & ~(i64)3;
-    for (i64 base = (i64)tid * 4; base < n4; base += (i64)4096 * U) {
-        float4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {   // unconditional loads (clamped), masked afterwards
-            const i64 i = min(base + (i64)u * 4096, n4 - 4);
-            x[u] = *reinterpret_cast<const float4*>(src + i);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const i64 i = base + (i64)u * 4096;
-            if (i < n4) { f(x[u].x, i); f(x[u].y, i + 1); f(x[u].z, i + 2); f(x[u].w, i + 3); }
-        }
-    }
-    if (tid == 0)
-        for (i64 i = n4; i < n_total; ++i) f(src[i], i);
-}
-
-__device__ __forceinline__ void select_threshold_topk(const float* __restrict__ src, i64 n_total, int K1, SelectScratch& S,
-                                                      u64* out)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // compared as ord32 images (the order of the packed keys: -0.0 sorts below +0.0 there, equal as floats); strict
-    // compare + ascending visit order keep the lowest index among equal values, i.e. the largest packed key
-    const u32 absent = ord32(-INFINITY);
-    u32 mo = absent;
-    i64 mi = 0;
-    select_visit(src, n_total, tid, [&](float x, i64 i) {
-        const u32 o = ord32(x);
-        const bool gt = o > mo;
-        mo = gt ? o : mo;
-        mi = gt ? i : mi;
-    });
-    const u64 tk = mo == absent ? 0ull : (((u64)mo << 32) | (u64)(0xFFFFFFFFu - (u32)mi));
-    S.tmax[tid] = tk;
-    if (tid == 0) S.cnt = 0;
-    if (tid < 64) out[tid] = 0ull;
-    __syncthreads();
-    if (wave == 0) {
-        u64 c[16];
-#pragma unroll
-        for (int n = 0; n < 16; ++n) c[n] = S.tmax[n * 64 + lane];
-        WaveListPacked L;
-        wave_topk_packed<16>(c, K1, L);
-        if (lane == 0) S.tau = L.kth(K1);   // 0 when fewer than K1 threads hold anything: every value is a candidate then
-    }
-    __syncthreads();
-    u64 tau = S.tau;
-    for (;;) {
-        if (tk != 0 && tk >= tau) {
-            const float tf = tau ? packed_value(tau) : -INFINITY;
-            select_visit(src, n_total, tid, [&](float x, i64 i) {
-                if (x >= tf && x != -INFINITY) {
-                    const u64 key = pack_key(x, (u32)i);
-                    if (key >= tau) {
-                        const int pos = atomicAdd(&S.cnt, 1);
-                        if (pos < kSelCap) S.cand[pos] = key;
-                    }
-                }
-            });
-        }
-        __syncthreads();
-        if (S.cnt <= kSelCap) break;
-        // more than kSelCap keys >= tau: bisect for a tau with K1 <= count <= kSelCap (counts move by one per key, so such
-        // a tau exists between blo, whose count is too large, and bhi, whose count is below K1)
-        u64 blo = tau, bhi = ~0ull;
-        for (;;) {
-            const u64 mid = blo + ((bhi - blo) >> 1);
-            __syncthreads();
-            if (tid == 0) S.cnt = 0;
-            __syncthreads();
-            int mine = 0;
-            if (tk >= mid)
-                select_visit(src, n_total, tid, [&](float x, i64 i) { mine += (x != -INFINITY && pack_key(x, (u32)i) >= mid) ? 1 : 0; });
-            if (mine) atomicAdd(&S.cnt, mine);
-            __syncthreads();
-            const int c2 = S.cnt;
-            if (c2 > kSelCap) blo = mid;
-            else if (c2 < K1) bhi = mid;
-            else { tau = mid; break; }
-        }
-        __syncthreads();
-        if (tid == 0) S.cnt = 0;
-        __syncthreads();
-    }
-    const int cnt = S.cnt;
-    if (tid < cnt) {   // rank by counting: keys are distinct
-        const u64 mine = S.cand[tid];
-        int r = 0;
-        for (int j = 0; j < cnt; ++j) r += S.cand[j] > mine ? 1 : 0;
-        if (r < K1) out[r] = mine;
     }
 }
 

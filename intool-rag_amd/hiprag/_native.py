@@ -26,7 +26,8 @@ class HipRagError(RuntimeError):
 class HipIdxStats(ctypes.Structure):
     _fields_ = [("passes", c_int64), ("queries", c_int64), ("fallback_queries", c_int64),
                 ("bytes_per_pass", c_int64), ("timed_passes", c_int64), ("avg_scan_ms", c_float),
-                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float), ("launches", c_int64), ("roundb_queries", c_int64)]
+                ("avg_scan_wall_ms", c_float), ("avg_scan_gap_ms", c_float), ("launches", c_int64), ("roundb_queries", c_int64),
+                ("list_entries", c_int64), ("ranked_entries", c_int64), ("rescored_groups", c_int64)]
 
 
 class HipBm25Stats(ctypes.Structure):
@@ -47,7 +48,6 @@ SIGNATURES = {
     "hiprag_event_create": [u64p],
     "hiprag_event_record": [c_uint64, c_void_p],
     "hiprag_probe_read_gbps": [c_int32, c_int64, c_int32, POINTER(c_double)],
-    "hiprag_select_topk_dev": [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     "hiprag_event_elapsed_ms": [c_uint64, c_uint64, f32p],
     "hiprag_event_destroy": [c_uint64],
     "hipidx_create": [c_int32, c_int32, c_int32, u64p],

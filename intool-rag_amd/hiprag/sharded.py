@@ -94,7 +94,7 @@ class ShardedFlatIndex:
         # HIPRAG_FORCE_EXCHANGE=1 runs it on a one-rank group as well (a single-GPU box can then exercise the RCCL calls)
         self.exchange = _exchange_on(self.world)
         local.set_id_base(row_lo)
-        if self.exchange and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+        if self.exchange:
             # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
             # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
             local.set_spare_cus(8)
@@ -299,7 +299,7 @@ class ShardedHybrid:
         self.exchange = _exchange_on(self.world)     # see ShardedFlatIndex
         dense.set_id_base(row_lo)
         bm25.set_id_base(row_lo)
-        if self.exchange and "HIPRAG_SCAN_SPARE_CUS" not in os.environ:
+        if self.exchange:
             dense.set_spare_cus(8)          # room for the all-gather kernel beside the next scan (ShardedFlatIndex)
         self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.exchange else None
         self._check_shapes = self.exchange and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
