@@ -6,10 +6,12 @@ Metric (BASELINE.json): queries/sec (+ p50 retrieve latency) for exact top-10 in
 1M x 1024-d fp32 index.  Workload = BASELINE configs[1]: "1M x 1024-d synthetic vectors, brute-force
 inner-product top-10".  A STEP is one pass of the hot path over one batch of synthetic queries already resident in
 HBM: ONE scan launch (8 passes of 64 queries at 1M rows; each pass streams the bf16 filter copy of the local rows
-once, HBM-bound) -> group select -> fp64 re-score of the fp32 rows + certificate (-> round B / exhaustive path where it
-fails) -> (N>1: one RCCL all-gather of the packed partial top-k + canonical merge).  Results are exact in every case.
+once, HBM-bound, and keeps a candidate list per query) -> ONE finish kernel: rank the list, fp64 re-score of the fp32 rows,
+certificate (-> exhaustive path where it fails) -> (N>1: one RCCL all-gather of the packed partial top-k + canonical
+merge).  Results are exact in every case.
 
-Multi-GPU (driver launches one rank per GPU through torch.distributed.run): the 1M rows are sharded row-wise
+Multi-GPU (one rank per GPU: the driver launches them through torch.distributed.run, and `python bench.py --gpus N` run bare
+starts them the same way itself; a world size other than --gpus is fatal): the 1M rows are sharded row-wise
 across the N ranks (STRONG scaling, total work fixed) and merged by one all-gather per step; up to four steps are
 in flight so the latency-bound tail of a step (selection, fp64 re-score, exchange, merge) runs beside later scans.
 The library sizes a launch by the local row count (16 passes = 1024 queries per step at <= 250k rows per GPU).
@@ -18,6 +20,9 @@ At N = 1 the same JSON line also carries `legs` (rank 0, after the headline sect
 resident in HBM; `--legs none` skips them, N > 1 never runs them):
   legs.fp32_stream  the SURVEY 8(d)-priced scan: HIPRAG_SCAN_MODE=q64 streams the fp32 rows (N*d*4 bytes per pass) instead of
                     the bf16 filter copy -- same exact results, the number the survey's byte accounting refers to
+  legs.reference_shape  the call shape the reference itself uses: L2 metric (faiss.IndexFlatL2, rag/storage/faiss_index.py:123), k = 50
+                    (page_retriever.py:81), ONE query per call (:81-83) -- p50 / p99 through hipidx_search with host arrays and through
+                    the overlay's search_hip_by_vector (enrichment included) -- plus batched L2 / k = 50 throughput and its roofline
   legs.hybrid       BASELINE configs[2]: 1M chunks, dense top-50 + BM25 term-at-a-time top-50 + RRF -> top-10; the BM25
                     roofline is priced on the posting bytes the queries REQUEST (sum df * 8 B), not on SURVEY 8(d)'s
                     accumulator passes, which the tiled kernel does not make
@@ -130,6 +135,108 @@ def run_legs(torch, args, dev, index, queries, legs):
         del sh, ix
         torch.cuda.empty_cache()
 
+    def leg_reference():
+        """The call shape the reference itself uses: faiss.IndexFlatL2 (rag/storage/faiss_index.py:123),
+        ONE query per search call (:81-83), k = 50 (rag/query/page_retriever.py:81) -- through the C-ABI with host arrays and
+        through the drop-in overlay (search_hip_by_vector: list in, enriched dicts out); plus batched L2 / k = 50 throughput
+        with its roofline (the norms stream is part of the bytes)."""
+        import asyncio
+        import tempfile
+        K = 50
+        ix = HipFlatIndex(DIM, "l2", device=dev.index)
+        ix.reserve_rows(n_rows)
+        for c in range((n_rows + chunk - 1) // chunk):
+            ix.add_device(gen_chunk(torch, c, min(chunk, n_rows - c * chunk), dev))
+        ix.reserve_search(K)
+        nwarm, nq1 = 20, 200
+        q_host = queries[:nwarm + nq1].cpu().numpy()
+        lat = []
+        for i in range(nwarm + nq1):                       # (a) hipidx_search: host query in, host results out, one per call
+            t1 = time.perf_counter()
+            ix.search(q_host[i:i + 1], K)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = np.sort(np.asarray(lat[nwarm:]))
+        # (b) the overlay: the resident index stands where the reference's path-keyed _INDEX_CACHE (faiss_index.py:24) would
+        # hold the loaded file; the chunk table is a real {doc}_chunks.json of n_rows chunks, parsed once and cached
+        tmp = tempfile.mkdtemp(prefix="hiprag_bench_")
+        old_storage = os.environ.get("STORAGE_DIR")
+        os.environ["STORAGE_DIR"] = tmp
+        import rag.storage.hip_index as hi
+        t1 = time.perf_counter()
+        with open(os.path.join(tmp, "bench_chunks.json"), "w") as f:
+            json.dump({"chunks": [{"chunk_id": f"c{i}", "text": f"chunk {i}", "page": 1 + i // 40,
+                                   "metadata": {"title": f"T{i // 40}", "source_filename": "bench.pdf"}} for i in range(n_rows)]}, f)
+        write_s = time.perf_counter() - t1
+        ipath = os.path.join(tmp, "bench" + hi.INDEX_SUFFIX)
+        open(ipath, "wb").close()
+        hi.clear_caches()
+        hi._INDEX_CACHE[ipath] = ix
+        q_lists = [q_host[i].tolist() for i in range(nwarm + nq1)]
+        t1 = time.perf_counter()
+        first = asyncio.run(hi.search_hip_by_vector(q_lists[0], limit=K))          # parses and caches the chunk table
+        first_s = time.perf_counter() - t1
+        lat_o = []
+        for i in range(nwarm + nq1):
+            t1 = time.perf_counter()
+            rows = asyncio.run(hi.search_hip_by_vector(q_lists[i], limit=K))
+            lat_o.append((time.perf_counter() - t1) * 1e3)
+        lat_o = np.sort(np.asarray(lat_o[nwarm:]))
+        ids_ok = [int(r["chunk_id"][1:]) for r in rows] == [int(v) for v in ix.search(q_host[nwarm + nq1 - 1:nwarm + nq1], K)[1][0]]
+        hi.clear_caches()
+        if old_storage is None:
+            del os.environ["STORAGE_DIR"]
+        else:
+            os.environ["STORAGE_DIR"] = old_storage
+        # (c) batched: the pipelined launches of the headline section, L2 metric and k = 50
+        sh = ShardedFlatIndex(ix, 0)
+        batch = ix.launch_queries
+        passes = (batch + ix.pass_queries - 1) // ix.pass_queries
+        nb = N_QUERIES // batch
+        from collections import deque
+
+        def steps(n, first_=0):
+            pending = deque()
+            for s_ in range(n):
+                b = (first_ + s_) % nb
+                pending.append(sh.search_begin(queries[b * batch:(b + 1) * batch], K))
+                if len(pending) >= 4:
+                    sh.search_end(pending.popleft())
+            while pending:
+                sh.search_end(pending.popleft())
+        steps(10)
+        torch.cuda.synchronize()
+        st0 = ix.stats()
+        ix.enable_timing(1)
+        torch.cuda.synchronize()
+        n = max(20, args.steps // 4)
+        t0 = time.perf_counter()
+        steps(n, 10)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = ix.stats()
+        ix.enable_timing(False)
+        bpl = int(st["bytes_per_pass"]) * passes
+        ach = bpl / (st["avg_scan_ms"] * 1e-3) / 1e9
+        nqs = max(1, int(st["queries"] - st0["queries"]))
+        out["reference_shape"] = {
+            "workload": f"the reference's call shape on {n_rows} x {DIM}: L2 metric (IndexFlatL2), k = {K}, one query per call",
+            "hipidx_search_p50_ms": round(float(lat[len(lat) // 2]), 4), "hipidx_search_p99_ms": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
+            "overlay_search_hip_by_vector_p50_ms": round(float(lat_o[len(lat_o) // 2]), 4),
+            "overlay_search_hip_by_vector_p99_ms": round(float(lat_o[int(len(lat_o) * 0.99) - 1]), 4),
+            "overlay_rows_returned": len(first), "overlay_ids_equal_hipidx_search": bool(ids_ok),
+            "chunk_table_first_load_s": round(first_s, 2), "chunk_table_write_s": round(write_s, 2), "queries_timed": nq1,
+            "batched": {"value": round(n * batch / el, 1), "unit": "queries/s", "k": K, "metric": "l2", "queries_per_step": batch,
+                        "ms_per_step": round(el / n * 1e3, 4),
+                        "extended_queries_share": round((st["roundb_queries"] - st0["roundb_queries"]) / nqs, 4),
+                        "fallback_queries": int(st["fallback_queries"] - st0["fallback_queries"]),
+                        "rescored_groups_per_query": round((st["rescored_groups"] - st0["rescored_groups"]) / nqs, 1),
+                        "roofline": {"bound": "hbm", "kernel": "scan_bf16_kernel<L2>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": bpl,
+                                     "bytes": "bf16 filter copy + the fp32 squared norms of every row, per pass",
+                                     "passes_per_launch": passes, "avg_launch_ms": round(float(st["avg_scan_ms"]), 5)}}}
+        del sh, ix
+        torch.cuda.empty_cache()
+
     def leg_hybrid():
         N, V, depth, nq = n_rows, 262144, 50, 256
         t0 = time.time()
@@ -161,7 +268,15 @@ def run_legs(torch, args, dev, index, queries, legs):
         b0 = bm25.stats()
         t_sparse = _time_steps(torch, lambda: bm25.search_device(sq, depth), 5, 2)
         b1 = bm25.stats()
+        d0 = index.stats()
         t_dense = _time_steps(torch, lambda: index.search_device(qd, depth), 5, 2)
+        d1 = index.stats()
+        dq = max(1, int(d1["queries"] - d0["queries"]))
+        dense_stats = {"extended_queries_share": round((d1["roundb_queries"] - d0["roundb_queries"]) / dq, 4),
+                       "fallback_queries": int(d1["fallback_queries"] - d0["fallback_queries"]),
+                       "list_entries_per_query": round((d1["list_entries"] - d0["list_entries"]) / dq, 1),
+                       "ranked_entries_per_query": round((d1["ranked_entries"] - d0["ranked_entries"]) / dq, 1),
+                       "rescored_groups_per_query": round((d1["rescored_groups"] - d0["rescored_groups"]) / dq, 1)}
         dl = index.search_device(qd, depth)
         sl = bm25.search_device(sq, depth)
         t_fuse = _time_steps(torch, lambda: rrf_fuse_device(dl[2], sl[2], TOPK), 20, 3)
@@ -179,9 +294,9 @@ def run_legs(torch, args, dev, index, queries, legs):
         post_per_q = (b1["postings_touched"] - b0["postings_touched"]) / (calls * nq)
         posting_gbs = post_per_q * 8 * (nq / t_sparse) / 1e9
         fetch = None
-        prof = os.path.join(REPO, "profiles", "r01_pmc_hybrid_fetch.json")
+        prof = os.path.join(REPO, "profiles", "r03_pmc_hybrid_fetch.json")
         if os.path.exists(prof):
-            fetch = {"source": "profiles/r01_pmc_hybrid_fetch.json (rocprofv3 --pmc FETCH_SIZE of the round-1 kernel; not collected "
+            fetch = {"source": "profiles/r03_pmc_hybrid_fetch.json (rocprofv3 --pmc FETCH_SIZE of THIS round's kernels; not collected "
                                "by this run)", "summary": json.load(open(prof)).get("kernels", {}).get("taat_tile_kernel")}
         out["hybrid"] = {"workload": f"configs[2]: {N} chunks, dense IP top-{depth} + BM25 TAAT top-{depth} + RRF -> top-{TOPK}, {nq} queries per call",
                          "value": round(nq / t_all, 1), "unit": "queries/s", "legs_overlapped_equal_sequential": same_fused,
@@ -189,10 +304,12 @@ def run_legs(torch, args, dev, index, queries, legs):
                          "bm25_qps": round(nq / t_sparse, 1), "rrf_qps": round(nq / t_fuse, 1),
                          "postings": int(postings.offsets[-1]), "postings_per_query": int(post_per_q),
                          "postings_build_s": round(build_s, 1),
-                         "bm25_roofline": {"bound": "hbm", "kernel": "taat_tile_kernel", "achieved": round(posting_gbs, 1),
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(posting_gbs / HBM_PEAK_GBS, 4),
-                                           "bytes": "posting bytes the queries request (sum of df x 8 B); most of them are served by L2 "
-                                                    "because frequent terms recur across a batch",
+                         "dense_top50_stats": dense_stats,
+                         "bm25_roofline": {"bound": "lds/issue", "kernel": "taat_tile_kernel",
+                                           "note": "not an HBM-bound kernel: a workgroup's time goes into LDS read-modify-write round "
+                                                   "trips and slot barriers (DESIGN 5); the figures below are the posting bytes the "
+                                                   "queries REQUEST (sum of df x 8 B) per second, most of which L2 serves",
+                                           "requested_GBs": round(posting_gbs, 1), "requested_over_hbm_peak": round(posting_gbs / HBM_PEAK_GBS, 4),
                                            "traffic_from_profile": fetch}}
         del bm25, postings
         torch.cuda.empty_cache()
@@ -216,7 +333,7 @@ def run_legs(torch, args, dev, index, queries, legs):
         torch.cuda.empty_cache()
 
     # a leg that fails must not cost the headline line: its entry carries the error instead
-    for name, fn in (("fp32", leg_fp32), ("hybrid", leg_hybrid), ("encoder", leg_encoder)):
+    for name, fn in (("fp32", leg_fp32), ("reference", leg_reference), ("hybrid", leg_hybrid), ("encoder", leg_encoder)):
         if name not in legs:
             continue
         try:
@@ -224,7 +341,7 @@ def run_legs(torch, args, dev, index, queries, legs):
         except Exception as e:
             import traceback
             print(f"[bench] leg {name} failed: {e!r}\n{traceback.format_exc()}", file=sys.stderr)
-            out[{"fp32": "fp32_stream"}.get(name, name)] = {"error": repr(e)}
+            out[{"fp32": "fp32_stream", "reference": "reference_shape"}.get(name, name)] = {"error": repr(e)}
             torch.cuda.empty_cache()
     return out
 
@@ -418,7 +535,7 @@ def main():
                          "ShardedHybrid (one packed all-gather per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--legs", default="fp32,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
+    ap.add_argument("--legs", default="fp32,reference,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     ap.add_argument("--force-dist", action="store_true",
@@ -635,6 +752,10 @@ def main():
         "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),
         "latency_path": "hipidx_search: host query in, host results out (H2D + scan + tails + D2H + sync) on the local shard",
         "fallback_queries": sum(r["fallback_queries"] for r in per_rank),
+        "finish_work_rank0": {"extended_queries_share": round(st["roundb_queries"] / max(1, st["queries"]), 4),
+                              "list_entries_per_query": round(st["list_entries"] / max(1, st["queries"]), 1),
+                              "ranked_entries_per_query": round(st["ranked_entries"] / max(1, st["queries"]), 1),
+                              "rescored_groups_per_query": round(st["rescored_groups"] / max(1, st["queries"]), 1)},
         "ranks_seen": len(per_rank),
         "per_rank": per_rank,
         "scan_ms_min_max": [min(r["scan_ms"] for r in per_rank), max(r["scan_ms"] for r in per_rank)],
@@ -709,14 +830,14 @@ def main():
             out.setdefault("cpu_baseline", {})["error"] = repr(e)
     # HBM traffic of the scan kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read from inside this
     # process); the committed summary applies to the full-size single-GPU workload only.
-    pmc = os.path.join(REPO, "profiles", "r02_pmc_scan.json")
+    pmc = os.path.join(REPO, "profiles", "r03_pmc_scan.json")
     if world == 1 and n_rows == N_ROWS and os.path.exists(pmc):
         with open(pmc) as f:
             p = json.load(f)
         # NOT measured in this run: counters cannot be read from inside the process.  `traffic` stays null; the number of the
         # committed PMC summary (same binary path, same workload) travels under a key that says where it comes from.
         out["roofline"]["traffic_from_profile"] = {"bytes_per_launch": int(p["traffic_bytes_per_launch"]),
-                                                   "source": "profiles/r02_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                   "source": "profiles/r03_pmc_scan.json (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                              "WRITE_SIZE, separate passes; not collected by this run)"}
     if world == 1 and args.legs != "none":
         del sharded

@@ -304,13 +304,17 @@ def test_extension_of_the_rescored_prefix_ties_and_overflow(gpu):
         assert st["roundb_queries"] >= 1 and 1 <= st["fallback_queries"] <= 2
 
 
-def test_full_size_1m_x_1024_properties(gpu):
-    """BASELINE configs[1] at full size (1M x 1024, top-10), where the CPU oracle would take minutes: size-independent
+@pytest.mark.parametrize("mode", ["bf16", "q64"])
+def test_full_size_1m_x_1024_properties(gpu, monkeypatch, mode):
+    """Both scan modes a number is quoted for (a wrong wait in the scan's load ring produces wrong scan values the
+    certificate cannot see, and only this full-size test catches them).
+    BASELINE configs[1] at full size (1M x 1024, top-10), where the CPU oracle would take minutes: size-independent
     properties instead -- (a) 256 planted queries (row + 5 % noise) find their row first, (b) every result list is sorted by
     (score desc, id asc) and repeats bit for bit, (c) eight row shards merged == the unsharded index bit for bit,
     (d) the top-10 of 8 queries equals an independent fp64 ranking computed chunk by chunk with torch on the GPU."""
     import torch
     from hiprag import HipFlatIndex, merge_topk_device
+    monkeypatch.setenv("HIPRAG_SCAN_MODE", mode)
     N, d, k, chunk = 1_000_000, 1024, 10, 125_000
     dev = torch.device("cuda", 0)
 
