@@ -400,7 +400,7 @@ def run_config3(torch, dist, args, world, rank, local_rank, dev, use_dist):
     del doc, term
     bm25 = HipBM25(postings, device=local_rank)
     n_postings = int(postings.offsets[-1])
-    hy = ShardedHybrid(index, bm25, row_lo)
+    hy = ShardedHybrid(index, bm25, row_lo, gather=gather_for(args.backend))
     torch.cuda.synchronize()
     build_s = time.time() - t0
 
@@ -496,6 +496,17 @@ def run_config3(torch, dist, args, world, rank, local_rank, dev, use_dist):
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gather_for(backend):
+    """None = the product's RCCL all_gather_into_tensor; the gloo rehearsals (two ranks sharing one GPU) need the list form."""
+    if backend == "nccl":
+        return None
+
+    def list_gather(pack, gathered, group=None, async_op=True):
+        import torch.distributed as dist
+        return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
+    return list_gather
 
 
 def launch_ranks(args) -> int:
@@ -624,7 +635,7 @@ def main():
         del x
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    sharded = ShardedFlatIndex(index, row_lo)
+    sharded = ShardedFlatIndex(index, row_lo, gather=gather_for(args.backend))
     index.reserve_search(TOPK)
 
     gq = torch.Generator(device=dev)

@@ -196,12 +196,34 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
 /* ---- hybrid fast path: one call = dense top-`depth` + BM25 top-`depth` + RRF -> top-k -------------------
  * What rag/query/retriever.py does per query batch with three calls, for hosts that bind the C-ABI directly: host
  * queries and term lists in, fused fp32 scores / ids out; the two result lists never leave the GPU.  Both handles must
- * live on the same device.  Row-sharded serving keeps using the three calls (the all-gather sits between search and
- * fusion, hiprag/sharded.py) -- ranks are global, so fusion has to follow the merge.  The BM25 leg runs on a library-owned helper stream beside the dense leg (they are independent; the
+ * live on the same device.  Row-sharded serving uses hiphybrid_shard_begin_dev / _end_dev below (the all-gather sits between
+ * search and fusion -- ranks are global, so fusion has to follow the merge).  The BM25 leg runs on a library-owned helper stream beside the dense leg (they are independent; the
  * dense scan is HBM-bound, BM25 is not) and RRF behind both. */
 int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
                          const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
                          float w_sparse, float* out_scores, int64_t* out_ids);
+
+/* ---- row-sharded hybrid step: the two halves around the caller's ONE all-gather (SURVEY 8b `hiphybrid_search(...)`, 8e) ----
+ * One process per GPU holds the rows AND the postings of one contiguous document range (hipidx_set_id_base /
+ * hipbm25_set_id_base make the ids global).  A batch is
+ *   hiphybrid_shard_begin_dev   local dense top-`depth` + local BM25 top-`depth` -> pack_dev, int64 [2 legs][2][nq][depth]
+ *                               (leg 0 dense, leg 1 BM25; [0] = fp64 score bits, [1] = ids).  The index scan is enqueued on
+ *                               scan_stream (callers chain their scans there), everything after it on tail_stream, ordered
+ *                               behind the scan by a library-owned event; `slot` (0..7) as in hipidx_search_begin_dev.
+ *                               scratch_f32_dev: 2 * nq * depth floats.
+ *   (caller)                    all-gather of pack_dev over the ranks -> gathered_dev [n_parts][2][2][nq][depth]: RCCL, MPI,
+ *                               whatever the host has; 4 * nq * depth * 8 bytes per rank
+ *   hiphybrid_shard_end_dev     each leg merged over the parts with the canonical comparator (better score, then lower id),
+ *                               RRF over the two GLOBAL lists -> out_scores_dev / out_ids_dev [nq][k], identical on every rank.
+ *                               scratch_dev: 4 * nq * depth int64.
+ * hiprag/sharded.py (ShardedHybrid) is one client of these two calls; a host without Python needs nothing else.
+ * The reference is a single CPU process (rag/storage/faiss_index.py:83, rag/Dockerfile:23-26): new capability. */
+int32_t hiphybrid_shard_begin_dev(uint64_t dense_h, uint64_t bm25_h, const float* q_dev, const uint32_t* term_ids_host,
+                                  const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t slot, int64_t* pack_dev,
+                                  float* scratch_f32_dev, void* scan_stream, void* tail_stream);
+int32_t hiphybrid_shard_end_dev(const int64_t* gathered_dev, int32_t n_parts, int32_t nq, int32_t depth, int32_t k,
+                                int32_t dense_metric, float c, float w_dense, float w_sparse, int64_t* scratch_dev,
+                                float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
 /* ---- batch encoder: XLM-RoBERTa-large architecture (BGE-M3 embeddings, bge-reranker-v2-m3 cross-encoder) ---------
  * forward     <- HuggingFaceEmbeddings.embed_query / embed_documents (sentence-transformers encode, CLS pooling,

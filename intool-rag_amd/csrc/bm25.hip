@@ -473,9 +473,8 @@ struct Bm25Index {
         HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots.data(), plan_nslots.size() * sizeof(int), hipMemcpyHostToDevice, st));
         if ((rc = theta_dev.reserve((size_t)nq * sizeof(u32)))) return rc;
         HR_CHECK_HIP(hipMemsetAsync(theta_dev.p, 0, (size_t)nq * sizeof(u32), st));
-        static const bool use_hist = [] { const char* e = getenv("HIPBM25_BOUND"); return !(e && e[0] == 't'); }();   // HIPBM25_BOUND=theta: round 1's bound only
         u32* hist_p = nullptr;
-        if (use_hist) {
+        {
             const size_t hbytes = (size_t)nq * (kHistBuckets + 1) * sizeof(u32);
             if ((rc = hist_dev.reserve(hbytes))) return rc;
             HR_CHECK_HIP(hipMemsetAsync(hist_dev.p, 0, hbytes, st));

@@ -204,7 +204,8 @@ constexpr int kCandCap = 4096;    // candidate-list entries per query in global 
 constexpr int kPublish = 4;       // blocks per published chunk
 constexpr int kDelay = 4;         // blocks between the end of a value's chunk and its test (publishers of other workgroups catch up)
 constexpr int kAge = kPublish - 1 + kDelay;   // chain position at which a value is tested
-constexpr int kStageCap = 768;    // staged appends per workgroup and pass (12 KiB of LDS); beyond that: direct global appends
+constexpr int kRecompute = 2;     // blocks between a chunk's publish and the recomputation of theta by the wave whose turn it is
+constexpr int kStageCap = 1792;   // staged appends per workgroup and pass (28 KiB of LDS); beyond that: direct global appends
 constexpr int kNoFilterGroups = 1024;   // indexes with at most this many groups list every group (= the finish's LDS list)
 
 struct Cand {       // one candidate group of one query, 16 bytes: staging entry and global list entry
@@ -281,20 +282,31 @@ __device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 
 }
 
 // ---- the in-register / in-LDS tail of both scan kernels --------------------------------------------------------------
-// LDS behind the query tile: Cand stage[kStageCap]; u32 stage_count.
+// LDS behind the query tile: Cand stage[kStageCap] | u32 ctl[16] (ctl[0] = staged entries, ctl[4 + s] = tag of bound slot s)
+// | u32 bound[kThetaBack][64] -- the workgroup's copy of the bounds of the last kThetaBack passes (slot = pass & 7, tag =
+// pass + 1), which is what the in-loop test reads: NO global load sits in the block loop.  (A per-block global read of
+// thetac did, at first: those lines are rewritten memory-side all the time, so the read misses L2, and because loads return
+// in order every ring re-arm issued behind it waited for it -- 0.43 ms of a 2.6 ms launch.)
+constexpr int kThetaBack = 8;    // passes a value can lag behind the pass its wave is in (kAge blocks / >= 1 block per pass)
+struct TailLds {
+    Cand* stage;
+    u32* ctl;
+    u32* bound;
+};
 struct ScanTail {
     float cf[2][kAge + 1], cs[2][kAge + 1];   // [query tile][age]: first / second of the last kAge + 1 blocks (shift chains)
     float pm0, pm1;                           // running maximum of `first` over the current chunk, per tile
     int t;                                    // blocks this wave has finished, over all passes
     int pa, ja;                               // pass and block offset of the value that is tested next
     int ev;                                   // publish events so far (the waves of a workgroup take turns recomputing theta)
+    int rc_due, rc_pass;                      // pending recomputation of theta: when (in blocks of this wave) and for which pass
 
     __device__ __forceinline__ void init()
     {
 #pragma unroll
         for (int i = 0; i <= kAge; ++i) { cf[0][i] = cf[1][i] = -FLT_MAX; cs[0][i] = cs[1][i] = -FLT_MAX; }
         pm0 = pm1 = -INFINITY;
-        t = 0; pa = 0; ja = 0; ev = 0;
+        t = 0; pa = 0; ja = 0; ev = 0; rc_due = -1; rc_pass = 0;
     }
 };
 
@@ -302,15 +314,62 @@ __device__ __forceinline__ u32 load_agent_u32(const u32* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// theta of the 64 queries of `pass` from their class slots (lane = query), folded into thetac
-__device__ __forceinline__ void recompute_theta(const ScanArgs& a, int pass, int lane)
+// memory-side read (a returning atomic): never served from an XCD's L2, hence never stale; ~88 requests per microsecond
+// and 64-byte line chip-wide, so only for rare paths
+__device__ __forceinline__ u32 load_memside_u32(u32* p)
 {
-    const u32* s = a.slots + (size_t)pass * kClasses * 64 + lane;
+    return __hip_atomic_fetch_or(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the workgroup's LDS copy of a pass's bound: lane = query; raises, never lowers, the copy of the same pass
+__device__ __forceinline__ void lds_put_bound(const TailLds& L, int pass, int lane, u32 v)
+{
+    const int slot = pass & (kThetaBack - 1);
+    if (L.ctl[4 + slot] == (u32)pass + 1u) {
+        if (v) atomicMax(L.bound + slot * 64 + lane, v);
+    } else {
+        L.bound[slot * 64 + lane] = v;
+        if (lane == 0) L.ctl[4 + slot] = (u32)pass + 1u;
+    }
+}
+__device__ __forceinline__ u32 lds_get_bound(const TailLds& L, int pass, int q_in_pass)
+{
+    const int slot = pass & (kThetaBack - 1);
+    return L.ctl[4 + slot] == (u32)pass + 1u ? L.bound[slot * 64 + q_in_pass] : 0u;
+}
+
+// theta of the 64 queries of `pass` from their class slots (lane = query), folded into thetac and into the LDS copy.
+// FRESH = memory-side reads (never stale, slow); otherwise sc1 loads, which the XCD's L2 may serve from a copy it fetched
+// earlier -- an older, LOWER maximum: still a valid bound, only less tight; an empty class means no update.
+template <bool FRESH>
+__device__ __forceinline__ u32 recompute_theta(const ScanArgs& a, const TailLds& L, int pass, int lane)
+{
+    u32* s = a.slots + (size_t)pass * kClasses * 64 + lane;
     u32 m = 0xFFFFFFFFu;
 #pragma unroll 16
-    for (int c = 0; c < a.ncls; ++c) m = min(m, load_agent_u32(s + c * 64));
-    if (m != 0 && pass * 64 + lane < a.nq) atomicMax(a.thetac + pass * 64 + lane, m);
+    for (int c = 0; c < a.ncls; ++c) m = min(m, FRESH ? load_memside_u32(s + c * 64) : load_agent_u32(s + c * 64));
+    if (pass * 64 + lane >= a.nq) m = 0;
+    if (m != 0) atomicMax(a.thetac + pass * 64 + lane, m);   // BEFORE anything is dropped against m: the final thetac bounds every drop
+    lds_put_bound(L, pass, lane, m);
+    return m;
+}
+
+// A wave that reaches the test of a pass's values before that pass's bound exists -- waves are not in lockstep, the front
+// runners of a launch are several blocks ahead of the rest -- would stage everything it holds (measured: a fifth of all
+// tests in multi-pass launches, 13 k entries per query).  It waits instead, bounded (60 us): it is ahead of the publishers
+// it waits for.  Polls are memory-side reads; the waiting wave recomputes theta itself, so the bound appears as soon as
+// every class has a publisher.
+__device__ __forceinline__ void wait_for_theta(const ScanArgs& a, const TailLds& L, int pass, int lane)
+{
+    const bool live = pass * 64 + lane < a.nq;
+    const unsigned long long t0 = wall_clock64();
+    for (int it = 0;; ++it) {
+        u32 v = load_memside_u32(a.thetac + pass * 64 + lane);    // another workgroup may have formed it already
+        if (__ballot(live && v == 0) && it) v = recompute_theta<true>(a, L, pass, lane);
+        if (!__ballot(live && v == 0)) { lds_put_bound(L, pass, lane, v); break; }
+        if (wall_clock64() - t0 > 6000ull) break;
+        if (it) __builtin_amdgcn_s_sleep(127);
+    }
 }
 
 // publish this wave's chunk maxima of `pass` (lane l ends up with the maximum of query 64 * pass + l)
@@ -320,7 +379,9 @@ __device__ __forceinline__ void publish_chunk(const ScanArgs& a, ScanTail& T, in
     const float v = lane < 32 ? x0 : x1;
     if (pass * 64 + lane < a.nq) atomicMax(a.slots + ((size_t)pass * kClasses + cls) * 64 + lane, ord32(v));
     T.pm0 = T.pm1 = -INFINITY;
-    if (my_turn) recompute_theta(a, pass, lane);
+    // theta is recomputed kRecompute blocks LATER: every workgroup publishes a chunk at about the same moment, and a
+    // recomputation right behind one's own publish finds classes whose publishers' atomics have not landed yet
+    if (my_turn) { T.rc_due = T.t + kRecompute; T.rc_pass = pass; }
     ++T.ev;
 }
 
@@ -330,36 +391,32 @@ __device__ __forceinline__ void append_direct(const ScanArgs& a, u64 key, float 
     if (p < (u32)kCandCap) a.list[(size_t)q * kCandCap + p] = Cand{key, sec, q};
 }
 
-__device__ __forceinline__ void stage_append(const ScanArgs& a, Cand* stage, u32* stage_count, u64 key, float sec, u32 q)
+__device__ __forceinline__ void stage_append(const ScanArgs& a, const TailLds& L, u64 key, float sec, u32 q)
 {
-    const u32 p = atomicAdd(stage_count, 1u);      // LDS atomic
-    if (p < (u32)kStageCap) stage[p] = Cand{key, sec, q};
+    const u32 p = atomicAdd(L.ctl, 1u);      // LDS atomic: returns on lgkmcnt, the hand-counted vmcnt ring never sees it
+    if (p < (u32)kStageCap) L.stage[p] = Cand{key, sec, q};
     else append_direct(a, key, sec, q);
 }
 
-// test the value at chain position `pos` (it belongs to block b0 + T.ja of pass T.pa) against thv = thetac of query
-// 64 * T.pa + lane, as loaded by lane `lane`; advance (pa, ja)
-__device__ __forceinline__ void test_aged(const ScanArgs& a, ScanTail& T, int pos_unused, float f0, float s0, float f1, float s1,
-                                          u32 thv, int lane, int64_t b0, int nbw, Cand* stage, u32* stage_count)
+// test one parked value pair (block b0 + T.ja of pass T.pa) against the bounds th0 / th1 of its two queries; advance (pa, ja)
+__device__ __forceinline__ void test_aged(const ScanArgs& a, ScanTail& T, const TailLds& L, float f0, float s0, float f1, float s1,
+                                          u32 th0, u32 th1, int lane, int64_t b0, int nbw)
 {
-    (void)pos_unused;
     const int b = lane & 31, h = lane >> 5;
-    const u32 th0 = (u32)__shfl((int)thv, b), th1 = (u32)__shfl((int)thv, 32 + b);
     const int q0 = T.pa * 64 + b, q1 = q0 + 32;
     const bool p0 = q0 < a.nq && ord32(f0) >= th0;
     const bool p1 = q1 < a.nq && ord32(f1) >= th1;
     if (__ballot(p0 || p1)) {   // wave-uniform: most blocks append nothing
         const u32 gid = (u32)(2 * (b0 + T.ja) + h);
-        if (p0) stage_append(a, stage, stage_count, pack_key(f0, gid), s0, (u32)q0);
-        if (p1) stage_append(a, stage, stage_count, pack_key(f1, gid), s1, (u32)q1);
+        if (p0) stage_append(a, L, pack_key(f0, gid), s0, (u32)q0);
+        if (p1) stage_append(a, L, pack_key(f1, gid), s1, (u32)q1);
     }
     if (++T.ja == nbw) { T.ja = 0; ++T.pa; }
 }
 
 // one finished block: park its four values, publish at chunk ends, test the value that has reached kAge
-__device__ __forceinline__ void tail_block(const ScanArgs& a, ScanTail& T, float f0, float s0, float f1, float s1, u32 thv, int pass,
-                                           int j, int nbw, int lane, int wave, int nwaves, int cls, int64_t b0, Cand* stage,
-                                           u32* stage_count)
+__device__ __forceinline__ void tail_block(const ScanArgs& a, ScanTail& T, const TailLds& L, float f0, float s0, float f1, float s1,
+                                           int pass, int j, int nbw, int lane, int wave, int nwaves, int cls, int64_t b0)
 {
 #pragma unroll
     for (int i = kAge; i > 0; --i) {
@@ -370,51 +427,69 @@ __device__ __forceinline__ void tail_block(const ScanArgs& a, ScanTail& T, float
     if (a.filter) {
         T.pm0 = fmaxf(T.pm0, f0);
         T.pm1 = fmaxf(T.pm1, f1);
-        if (((j + 1) & (kPublish - 1)) == 0 || j == nbw - 1) publish_chunk(a, T, pass, lane, cls, T.ev % nwaves == wave);
+        // after the FIRST block of a range (the bound of a pass can form as early as possible), then every kPublish blocks
+        if ((j & (kPublish - 1)) == 0 || j == nbw - 1) publish_chunk(a, T, pass, lane, cls, T.ev % nwaves == wave);
     }
-    if (T.t >= kAge) test_aged(a, T, kAge, T.cf[0][kAge], T.cs[0][kAge], T.cf[1][kAge], T.cs[1][kAge], thv, lane, b0, nbw, stage, stage_count);
+    if (T.t >= kAge) {
+        const int b = lane & 31;
+        u32 th0 = 0, th1 = 0;
+        if (a.filter) {
+            th0 = lds_get_bound(L, T.pa, b);
+            th1 = lds_get_bound(L, T.pa, 32 + b);
+            if (__ballot((th0 == 0 && T.pa * 64 + b < a.nq) || (th1 == 0 && T.pa * 64 + 32 + b < a.nq))) {
+                wait_for_theta(a, L, T.pa, lane);
+                th0 = lds_get_bound(L, T.pa, b);
+                th1 = lds_get_bound(L, T.pa, 32 + b);
+            }
+        }
+        test_aged(a, T, L, T.cf[0][kAge], T.cs[0][kAge], T.cf[1][kAge], T.cs[1][kAge], th0, th1, lane, b0, nbw);
+    }
+    if (T.rc_due >= 0 && T.t >= T.rc_due) { recompute_theta<false>(a, L, T.rc_pass, lane); T.rc_due = -1; }
     ++T.t;
 }
 
-// staged appends -> the queries' global lists (whole workgroup, between two barriers)
+// The workgroup's bounds of the last kThetaBack passes, refreshed from global memory (memory-side: fresh whatever the XCD's
+// L2 holds) -- once per workgroup and pass, in the pass prologue.  (Read per staged entry instead, 150 k same-line atomics
+// per pass saturated the four lines the bounds of a pass live on: ~88 requests per microsecond and line.)
+__device__ __forceinline__ void refresh_bounds(const ScanArgs& a, const TailLds& L, int pass_now, int wave, int nwaves, int lane)
+{
+    if (!a.filter) return;
+    for (int w = wave; w < kThetaBack; w += nwaves) {
+        const int p = pass_now - w;
+        if (p >= 0) lds_put_bound(L, p, lane, load_memside_u32(a.thetac + p * 64 + lane));
+    }
+}
+// staged appends -> the queries' global lists (whole workgroup, between barriers).  Every entry is tested AGAIN, against
+// what its query's bound has become since it was staged: the in-loop test runs a few blocks behind the publishers, when
+// the bound of a pass is still forming (a wave that runs ahead tests against the publishes of the other fast waves only --
+// measured 0.6-1.1 k staged entries per query at 1M rows where the final bound admits 0.3 k); the flush runs a pass later,
+// or at the end of the launch.
 template <int NT>
-__device__ __forceinline__ void flush_stage(const ScanArgs& a, const Cand* stage, int n, int tid)
+__device__ __forceinline__ void flush_stage(const ScanArgs& a, const TailLds& L, int n, int tid)
 {
     for (int i = tid; i < n; i += NT) {
-        const Cand e = stage[i];
-        append_direct(a, e.key, e.sec, e.q);
+        const Cand e = L.stage[i];
+        if ((u32)(e.key >> 32) >= lds_get_bound(L, (int)(e.q >> 6), (int)(e.q & 63))) append_direct(a, e.key, e.sec, e.q);
     }
 }
 
-// after the last block of the last pass: rendezvous (bounded), final theta, test what is still in the chains
-__device__ __forceinline__ void tail_drain(const ScanArgs& a, ScanTail& T, int lane, int64_t b0, int nbw, Cand* stage, u32* stage_count)
+// after the last block of the last pass: test what is still in the chains against the bound as it stands (no rendezvous: a
+// wave that ends early misses the last chunks of the late ones -- a slightly lower bound, a few per cent more entries)
+__device__ __forceinline__ void tail_drain(const ScanArgs& a, ScanTail& T, const TailLds& L, int lane, int64_t b0, int nbw)
 {
-    if (a.filter) {
-        // every wave has published its last chunk before it arrives; the wait is bounded (a workgroup that starts late --
-        // its CU was still running a tail kernel of an earlier launch -- costs list length, not correctness or progress)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        for (;;) {
-            const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)load_agent_u32(a.arrive));
-            if (n >= (u32)a.n_active || wall_clock64() - t0 > 20000ull) break;   // 200 us at 100 MHz
-            __builtin_amdgcn_s_sleep(32);
-        }
-    }
     const int R = T.t < kAge ? T.t : kAge;   // values still untested: chain positions R - 1 .. 0
+    if (a.filter && T.rc_due >= 0) { recompute_theta<true>(a, L, T.rc_pass, lane); T.rc_due = -1; }
     int pa_loaded = -1;
-    u32 thv = 0;
+    const int b = lane & 31;
 #pragma unroll
     for (int pos = kAge - 1; pos >= 0; --pos) {
         if (pos < R) {
-            if (T.pa != pa_loaded) {
-                if (a.filter) {
-                    recompute_theta(a, T.pa, lane);
-                    thv = load_agent_u32(a.thetac + T.pa * 64 + lane);
-                }
+            if (a.filter && T.pa != pa_loaded) {   // the flush tests every staged entry again, against a refreshed copy
+                lds_put_bound(L, T.pa, lane, load_memside_u32(a.thetac + T.pa * 64 + lane));
                 pa_loaded = T.pa;
             }
-            test_aged(a, T, pos, T.cf[0][pos], T.cs[0][pos], T.cf[1][pos], T.cs[1][pos], thv, lane, b0, nbw, stage, stage_count);
+            const u32 th0 = a.filter ? lds_get_bound(L, T.pa, b) : 0u, th1 = a.filter ? lds_get_bound(L, T.pa, 32 + b) : 0u;
+            test_aged(a, T, L, T.cf[0][pos], T.cs[0][pos], T.cf[1][pos], T.cs[1][pos], th0, th1, lane, b0, nbw);
         }
     }
 }
@@ -546,11 +621,12 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     const int S = nbw * (PIECES_PER_BLOCK);                                                                              \
     const float4* base = (BASE_PTR);                                                                                     \
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();                                                        \
-    Cand* stage = reinterpret_cast<Cand*>(reinterpret_cast<char*>(qs) + (size_t)a.P * 1024);                             \
-    u32* stage_count = reinterpret_cast<u32*>(stage + kStageCap);                                                        \
-    if (tid == 0) *stage_count = 0;                                                                                      \
-    const int cls = (int)(gw % a.ncls);                                                                                  \
-    const unsigned lane4 = (unsigned)lane * 4u;                                                                          \
+    TailLds L;                                                                                                           \
+    L.stage = reinterpret_cast<Cand*>(reinterpret_cast<char*>(qs) + (size_t)a.P * 1024);                                 \
+    L.ctl = reinterpret_cast<u32*>(L.stage + kStageCap);                                                                 \
+    L.bound = L.ctl + 16;                                                                                                \
+    if (tid < 16) L.ctl[tid] = 0;                                                                                        \
+    const int cls = (int)((gw + blockIdx.x) % a.ncls); /* members of a class on every XCD and every wave slot */           \
     ScanTail T;                                                                                                          \
     T.init()
 
@@ -561,20 +637,23 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     int nstaged = 0;                                                                                                     \
     if (pass) {                                                                                                          \
         __syncthreads(); /* every wave is done with the previous tile and with its staged appends */                     \
-        nstaged = min((int)*stage_count, kStageCap);                                                                     \
+        nstaged = min((int)L.ctl[0], kStageCap);                                                                         \
+        refresh_bounds(a, L, pass - 1, wave, NWAVES, lane);                                                              \
     }                                                                                                                    \
     stage_query_tile<NT>(a, reinterpret_cast<bf16x8*>(qs), P2, qbase, tid);                                              \
     if (pass) {                                                                                                          \
-        __syncthreads(); /* everybody has read the count */                                                              \
-        if (tid == 0) *stage_count = 0;                                                                                  \
-        flush_stage<NT>(a, stage, nstaged, tid);                                                                         \
+        __syncthreads(); /* everybody has read the count; the bounds are in LDS */                                       \
+        if (tid == 0) L.ctl[0] = 0;                                                                                      \
+        flush_stage<NT>(a, L, nstaged, tid);                                                                             \
     }                                                                                                                    \
     __syncthreads()
 
 #define HIPRAG_SCAN_EPILOGUE()                                                                                           \
-    if (S > 0) tail_drain(a, T, lane, b0, nbw, stage, stage_count);                                                      \
+    if (S > 0) tail_drain(a, T, L, lane, b0, nbw);                                                                       \
     __syncthreads();                                                                                                     \
-    flush_stage<NT>(a, stage, min((int)*stage_count, kStageCap), tid);                                                   \
+    refresh_bounds(a, L, npass - 1, wave, NWAVES, lane);                                                                 \
+    __syncthreads();                                                                                                     \
+    flush_stage<NT>(a, L, min((int)L.ctl[0], kStageCap), tid);                                                           \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the tail's clamped re-arms are still in flight */                \
     if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64()
 
@@ -603,12 +682,6 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
         bf16x8 n0v = q0[lane], n1v = q1[lane];   // query fragments are read one piece ahead
         for (int j = 0; j < nbw; ++j) {
             const int64_t blk = b0 + j;
-            // thetac of the queries whose values reach the test at the end of this block; waited for with the norms
-            u32 thv;
-            {
-                const u32* tp = a.thetac + T.pa * 64;
-                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(thv) : "v"(lane4), "s"(tp) : "memory");
-            }
             f32x4 nrm[4];
             if (METRIC == HIPRAG_METRIC_L2) {
 #pragma unroll
@@ -643,17 +716,14 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
                 }
                 s += RING;
             }
-            // thetac and the norms were issued before this block's P2 >= RING re-arms
-            if (METRIC == HIPRAG_METRIC_L2)
-                asm volatile("s_waitcnt vmcnt(%5)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]), "+v"(thv) : "n"(RING) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(thv) : "n"(RING) : "memory");
+            if (METRIC == HIPRAG_METRIC_L2)   // the norms were issued before this block's P2 >= RING re-arms
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
             float sec0, sec1;
             int lane_b = lane;
             asm volatile("" : "+v"(lane_b));   // (as in stage_query_tile: keeps the epilogue's lane arithmetic out of the ring loop's live set)
             const float fst0 = block_lane_top2<METRIC>(acc0, nrm, blk, lane_b >> 5, a, sec0);
             const float fst1 = block_lane_top2<METRIC>(acc1, nrm, blk, lane_b >> 5, a, sec1);
-            tail_block(a, T, fst0, sec0, fst1, sec1, thv, pass, j, nbw, lane_b, wave, NWAVES, cls, b0, stage, stage_count);
+            tail_block(a, T, L, fst0, sec0, fst1, sec1, pass, j, nbw, lane_b, wave, NWAVES, cls, b0);
         }
     }  // pass
     HIPRAG_SCAN_EPILOGUE();
@@ -688,7 +758,8 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         int nstaged = 0;
         if (pass) {
             __syncthreads();
-            nstaged = min((int)*stage_count, kStageCap);
+            nstaged = min((int)L.ctl[0], kStageCap);
+            refresh_bounds(a, L, pass - 1, wave, NWAVES, lane);
         }
         {
             u32x4* qw = reinterpret_cast<u32x4*>(qs);
@@ -725,8 +796,8 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         }
         if (pass) {
             __syncthreads();
-            if (tid == 0) *stage_count = 0;
-            flush_stage<NT>(a, stage, nstaged, tid);
+            if (tid == 0) L.ctl[0] = 0;
+            flush_stage<NT>(a, L, nstaged, tid);
         }
         __syncthreads();
         if (S <= 0) continue;
@@ -735,11 +806,6 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
         bf16x8 n0v = q0[lane], n1v = q1[lane];
         for (int j = 0; j < nbw; ++j) {
             const int64_t blk = b0 + j;
-            u32 thv;
-            {
-                const u32* tp = a.thetac + T.pa * 64;
-                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(thv) : "v"(lane4), "s"(tp) : "memory");
-            }
             f32x4 nrm[4];
             if (METRIC == HIPRAG_METRIC_L2) {
 #pragma unroll
@@ -785,15 +851,13 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
                 s += RING;
             }
             if (METRIC == HIPRAG_METRIC_L2)
-                asm volatile("s_waitcnt vmcnt(%5)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]), "+v"(thv) : "n"(RING) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(thv) : "n"(RING) : "memory");
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]), "+v"(nrm[3]) : "n"(RING) : "memory");
             float sec0, sec1;
             int lane_b = lane;
             asm volatile("" : "+v"(lane_b));
             const float fst0 = block_lane_top2<METRIC>(acc0, nrm, blk, lane_b >> 5, a, sec0);
             const float fst1 = block_lane_top2<METRIC>(acc1, nrm, blk, lane_b >> 5, a, sec1);
-            tail_block(a, T, fst0, sec0, fst1, sec1, thv, pass, j, nbw, lane_b, wave, NWAVES, cls, b0, stage, stage_count);
+            tail_block(a, T, L, fst0, sec0, fst1, sec1, pass, j, nbw, lane_b, wave, NWAVES, cls, b0);
         }
     }  // pass
     HIPRAG_SCAN_EPILOGUE();
@@ -995,7 +1059,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
     }
     __syncthreads();
     // 7. (early: everything of the scan state has been read) leave the slot clean for its next launch
-    if (tid == 0) { a.count[q] = 0; a.thetac[q] = 0; if (q == 0) *a.arrive = 0; }
+    if (tid == 0) { a.count[q] = 0; a.thetac[q] = 0; }
     if (tid < kClasses) a.slots[((size_t)(q >> 6) * kClasses + tid) * 64 + (q & 63)] = 0;
     const int n = s_n;
     bool flag = cnt_raw > (u32)kCandCap || n > kListLds;
@@ -1488,7 +1552,7 @@ struct DenseIndex {
             sa.ncls = std::max(1, std::min(kClasses, sa.n_active));
             if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2, 0, (size_t)scan_cus * kMaxScanWaves * 16, st));
             sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2 : nullptr;
-            const size_t scan_lds = (size_t)P * 1024 + (size_t)kStageCap * sizeof(Cand) + 16;  // query tile + staged appends
+            const size_t scan_lds = (size_t)P * 1024 + (size_t)kStageCap * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
             const bool one_pass = nq <= kPassQ;
             void (*scan)(ScanArgs);
             if (scan_mode == 3) {
@@ -1796,6 +1860,20 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
     if (rc) return rc;
     HR_CHECK_HIP(hipMemcpy(out_scores, ix->o32.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     HR_CHECK_HIP(hipMemcpy(out_ids, ix->oid.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HIPRAG_OK;
+}
+
+// DEBUG (not in the header): the scan state of a slot after a begin without its finish -- count[Q], thetac[Q], slots[Q/64][64][64]
+int32_t hipidx_debug_scan_state(uint64_t h, int32_t slot, uint32_t* out_count, uint32_t* out_thetac, uint32_t* out_slots, int32_t* out_q, uint32_t* out_arrive)
+{
+    GET_INDEX(h);
+    HR_CHECK_HIP(hipDeviceSynchronize());
+    DenseIndex::Workspace& w = ix->ws[slot];
+    *out_q = w.q;
+    HR_CHECK_HIP(hipMemcpy(out_count, DenseIndex::st_count(w), (size_t)w.q * 4, hipMemcpyDeviceToHost));
+    HR_CHECK_HIP(hipMemcpy(out_thetac, DenseIndex::st_thetac(w), (size_t)w.q * 4, hipMemcpyDeviceToHost));
+    HR_CHECK_HIP(hipMemcpy(out_arrive, DenseIndex::st_arrive(w), 64, hipMemcpyDeviceToHost));
+    HR_CHECK_HIP(hipMemcpy(out_slots, DenseIndex::st_slots(w), (size_t)(w.q / 64) * 4096 * 4, hipMemcpyDeviceToHost));
     return HIPRAG_OK;
 }
 

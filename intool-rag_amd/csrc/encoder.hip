@@ -17,7 +17,7 @@
 //            -> fp32 pre-LayerNorm buffer)
 //            gemm_skinny_kernel: the same products for <= 384 token rows (one query, a few short texts) as
 //            weight-streaming workgroups of 16/32 columns; split-K partials are summed by the LayerNorm
-//   K7  attention_kernel     flash-style, computed transposed: 128 queries x 64-key tiles, online softmax in fp32, P stays in registers
+//   K7  attention2_kernel    flash-style, computed transposed: 128 queries x 32-key tiles, online softmax in fp32, P stays in registers
 //       layernorm_kernel     fp32 pre-LN rows -> bf16
 //   K10 pool_kernel / rerank_head_kernel
 // LDS tiles are stored k-chunk-major ([k/8][row][8 bf16]) with row ^= (chunk & 7): fragment reads (ds_read_b128) and
@@ -569,157 +569,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ t
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K7: attention.  grid (ceil(S/128), heads, nseq); 4 waves x 32 queries; keys in tiles of 64.
-// q,k: [nseq, heads, S, 64] (q pre-scaled by 1/8), vt: [nseq, heads, 64, S]; ctx out: [M, H] row-major.
-// Everything is computed TRANSPOSED so that the probabilities never leave registers:
-//   S^T tile  D[key 4kq + r][query r16] = K fragment (A operand, from LDS) x Q fragment (B operand, registers)
-//   O^T      D[d   4kq + r][query r16] += V^T fragment (A, from LDS) x P^T fragment (B) -- and the B operand of a 32-key
-//            slab is exactly what the lane already holds of two S^T tiles: keys 32s + 4kq + 0..3 and 32s + 16 + 4kq + 0..3.
-//            The contraction order inside an MFMA is free as long as A and B agree, so the V^T fragment is read as those
-//            two 8-byte key groups instead of one 16-byte run.
-// A lane therefore owns ONE query column: running max / sum are per-lane scalars (two xor-shuffles across the kq lanes
-// per tile), and the output is 4 consecutive d per lane -> 8-byte stores.  K / V^T tiles are fetched into registers one
-// tile ahead (global latency under the MFMAs) and written to LDS between two barriers.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                       const bf16* __restrict__ vt, const int* __restrict__ lens,
-                                                       bf16* __restrict__ ctx, int S, int heads, int H)
-{
-    __shared__ bf16x8 kl[64 * 8];        // K tile  [d/8][key][8], swizzled
-    __shared__ bf16x8 vl[64 * 8];        // V^T tile [key/8][d][8], swizzled
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int seq = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
-    const int len = lens[seq];
-    if (q0 >= len) return;  // whole query tile is padding
-    const size_t hb = (size_t)seq * heads + head;
-    const bf16* qh = q + hb * S * 64;
-    const bf16* kh = k + hb * S * 64;
-    const bf16* vh = vt + hb * 64 * S;
-
-    // Q fragments (B operand): lane (query r16, kq) holds Q[query][32 ks + 8 kq .. +7]; two query tiles per wave
-    bf16x8 qf[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int qi = min(q0 + wave * 32 + t * 16 + r16, S - 1);   // S is a multiple of 64, the tile covers 128
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qh + (size_t)qi * 64 + ks * 32 + kq * 8);
-    }
-    f32x4 o[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
-    const float LOG2E = 1.4426950408889634f;
-
-    // tile prefetch registers: 512 16-B chunks per operand tile, 2 per thread
-    bf16x8 pk[2], pv[2];
-    auto prefetch = [&](int kt0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 3, kc = c & 7;
-            pk[i] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kt0 + row) * 64 + kc * 8);
-            pv[i] = *reinterpret_cast<const bf16x8*>(vh + (size_t)row * S + kt0 + kc * 8);
-        }
-    };
-    prefetch(0);
-    for (int kt0 = 0; kt0 < len; kt0 += 64) {
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 3, kc = c & 7;
-            kl[swz_unit(kc, row, 64)] = pk[i];
-            vl[swz_unit(kc, row, 64)] = pv[i];
-        }
-        __syncthreads();
-        if (kt0 + 64 < len) prefetch(kt0 + 64);   // in flight under this tile's MFMAs
-        // S^T: sc[t][j][r] = score(key kt0 + 16j + 4kq + r, query tile t column r16)
-        f32x4 sc[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16x8 k0 = kl[swz_unit(kq, j * 16 + r16, 64)];
-            const bf16x8 k1 = kl[swz_unit(4 + kq, j * 16 + r16, 64)];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                sc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[t][1], a, 0, 0, 0);
-            }
-        }
-        // mask padded keys, online softmax (one query per lane)
-        bf16x8 pf[2][2];   // P^T fragments: [query tile][key slab of 32]
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (kt0 + j * 16 + 4 * kq + r >= len) sc[t][j][r] = -INFINITY;
-                    tmax = fmaxf(tmax, sc[t][j][r]);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float mn = fmaxf(mrow[t], tmax);   // finite: key 0 of the first tile is always valid
-            const float alpha = __builtin_amdgcn_exp2f((mrow[t] - mn) * LOG2E);
-            mrow[t] = mn;
-            float psum = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f((sc[t][2 * s + h][r] - mn) * LOG2E);
-                        psum += p;
-                        pf[t][s][4 * h + r] = (bf16)p;
-                    }
-            psum += __shfl_xor(psum, 16);
-            psum += __shfl_xor(psum, 32);
-            lrow[t] = lrow[t] * alpha + psum;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[t][j][r] *= alpha;
-        }
-        // O^T += V^T P^T: A fragment of d-tile j, slab s = V^T[d = 16j + r16][keys 32s + 4kq + 0..3, 32s + 16 + 4kq + 0..3]
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                const int d = j * 16 + r16;
-                const bf16x4 lo = reinterpret_cast<const bf16x4*>(&vl[swz_unit(4 * s + (kq >> 1), d, 64)])[kq & 1];
-                const bf16x4 hi = reinterpret_cast<const bf16x4*>(&vl[swz_unit(4 * s + 2 + (kq >> 1), d, 64)])[kq & 1];
-                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) o[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][s], o[t][j], 0, 0, 0);
-            }
-    }
-    // o[t][j][r] = out(query q0 + wave*32 + 16t + r16, d = 16j + 4kq + r) * l
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int qi = q0 + wave * 32 + t * 16 + r16;
-        if (qi >= S) continue;
-        const float inv = 1.f / lrow[t];
-        bf16* dst = ctx + ((size_t)seq * S + qi) * H + head * 64 + 4 * kq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[t][j][r] * inv);
-            *reinterpret_cast<bf16x4*>(dst + j * 16) = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// K7, second form (the default): the same transposed flash attention on v_mfma_f32_32x32x16_bf16 with LDS-DMA staging.
-// What the first form spent its time on was not the matrix pipe (0.17 busy, r01) but ~550 vector instructions per 64-key
-// tile and wave: the key mask, the rescale of the output accumulators and their trips to and from the accumulator file on
+// K7: attention -- transposed flash attention on v_mfma_f32_32x32x16_bf16 with LDS-DMA staging.
+// q,k: [nseq, heads, S, 64] (q pre-scaled by 1/8), vt: [nseq, heads, 64, S]; ctx out: [M, H] row-major.  Everything is computed
+// TRANSPOSED (S^T = K Q^T, O^T = V^T P^T) so that the probabilities never leave registers.
+// What round 1's kernel (16x16x32 MFMAs, register staging; removed in round 3) spent its time on was not the matrix pipe
+// (0.17 busy, r01) but ~550 vector instructions per 64-key tile and wave: the key mask, the rescale of the output accumulators and their trips to and from the accumulator file on
 // EVERY tile, three operations per exponential, four cross-lane shuffles per tile, K / V tiles hauled global -> registers
 // -> LDS between two barriers.  Here:
 //   * a wave owns ONE tile of 32 queries; S^T = K Q^T puts a query on lanes q and q + 32, each holding 16 of a 32-key
@@ -939,7 +793,6 @@ struct Encoder {
 
     int n_cu = 256;
     int use256 = 1;          // HIPENC_GEMM256=0 keeps every batch on the 128 x 128 kernel (A/B runs)
-    int attn_v1 = 0;         // HIPENC_ATTN_V1=1: the first attention kernel (16x16x32 MFMAs, register staging) for A/B runs
 
     // the 256 x 256 persistent kernel: whole 256-tiles in M and N, an even number of k-tiles, and enough tiles to fill the CUs
     bool big_ok(int M, int N, int K) const
@@ -1038,12 +891,7 @@ struct Encoder {
             if (small) launch_skinny<EPI_QKV>(g, st);
             else if (big) launch256<EPI_QKV>(g, M, st);
             else hipLaunchKernelGGL(gemm_bf16_kernel<EPI_QKV>, dim3((3 * H / BN) * (M / BM)), dim3(kGemmThreads), 0, st, g);
-            if (attn_v1)
-                hipLaunchKernelGGL(attention_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
-                                   (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
-                                   heads, H);
-            else
-                hipLaunchKernelGGL(attention2_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
+            hipLaunchKernelGGL(attention2_kernel, dim3((S + 127) / 128, heads, nseq), dim3(256), 0, st, (const bf16*)q.as<bf16>(),
                                    (const bf16*)k.as<bf16>(), (const bf16*)vt.as<bf16>(), (const int*)lens.as<int>(), ctx.as<bf16>(), S,
                                    heads, H);
             GemmArgs o{};
@@ -1151,7 +999,6 @@ int32_t hipenc_create(const hipenc_config* cfg, const hipenc_weights* weights, i
     e->layers.assign(weights->layers, weights->layers + cfg->layers);
     if (const char* sr = std::getenv("HIPENC_SMALL_ROWS")) e->small_rows = std::atoi(sr);
     if (const char* g2 = std::getenv("HIPENC_GEMM256")) e->use256 = std::atoi(g2);
-    if (const char* a1 = std::getenv("HIPENC_ATTN_V1")) e->attn_v1 = std::atoi(a1);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cu = cus;

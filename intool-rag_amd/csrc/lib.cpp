@@ -85,6 +85,37 @@ struct SideLease {
     }
 };
 
+struct StepEvents {    // one event per (device, slot): orders a step's tail stream behind its scan
+    std::mutex mu;
+    std::unordered_map<long long, hipEvent_t> ev;
+    int32_t get(int dev, int slot, hipEvent_t& out)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        const long long key = (long long)dev * 64 + slot;
+        auto it = ev.find(key);
+        if (it == ev.end()) {
+            hipEvent_t e = nullptr;
+            HR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            it = ev.emplace(key, e).first;
+        }
+        out = it->second;
+        return HIPRAG_OK;
+    }
+    void clear()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& kv : ev) {
+            if (hipSetDevice((int)(kv.first / 64)) == hipSuccess) (void)hipEventDestroy(kv.second);
+        }
+        ev.clear();
+    }
+};
+static StepEvents& step_events()
+{
+    static StepEvents s;
+    return s;
+}
+
 namespace {
 // hiprag_probe_read_gbps: what this device streams through a statically partitioned read (the dense scan's access
 // pattern without its work): every wave reads its own contiguous range of 64 KiB blocks, 16 KiB in flight per wave,
@@ -159,6 +190,7 @@ int32_t hiprag_shutdown(void)
     clear_dense_registry();
     events().clear();
     side_pool().clear();
+    step_events().clear();
     return HIPRAG_OK;
 }
 
@@ -241,6 +273,58 @@ int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host,
     HR_CHECK_HIP(hipMemcpy(out_ids, oi.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
     lease.busy = false;   // the blocking copies above ran behind the fusion, which waited for the BM25 leg
     return HIPRAG_OK;
+}
+
+// ---- row-sharded hybrid step: the library's two halves around the caller's ONE all-gather ----------------
+
+int32_t hiphybrid_shard_begin_dev(uint64_t dense_h, uint64_t bm25_h, const float* q_dev, const uint32_t* term_ids_host,
+                                  const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t slot, int64_t* pack_dev,
+                                  float* scratch_f32_dev, void* scan_stream, void* tail_stream)
+{
+    HR_REQUIRE(nq > 0 && depth > 0, "bad hybrid shape");
+    HR_REQUIRE(q_dev && q_offsets_host && pack_dev && scratch_f32_dev, "null argument");
+    int32_t rc;
+    // the HBM-heavy part stays on the caller's scan stream (scans chained one after the other) ...
+    if ((rc = hipidx_search_begin_dev(dense_h, q_dev, nq, depth, slot, scan_stream))) return rc;   // makes the device current
+    int dev = 0;
+    HR_CHECK_HIP(hipGetDevice(&dev));
+    hipEvent_t scanned = nullptr;
+    if ((rc = step_events().get(dev, slot, scanned))) return rc;
+    if (tail_stream != scan_stream) {
+        HR_CHECK_HIP(hipEventRecord(scanned, (hipStream_t)scan_stream));
+        HR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)tail_stream, scanned, 0));
+    }
+    // ... everything latency-bound on the tail stream, beside later scans: the dense finish and the BM25 leg fill the two
+    // halves of the pack, [leg][score bits | ids][nq][depth]
+    const size_t leg = (size_t)2 * nq * depth;
+    if ((rc = hipidx_search_finish_dev(dense_h, q_dev, nq, depth, slot, reinterpret_cast<double*>(pack_dev), scratch_f32_dev,
+                                       pack_dev + (size_t)nq * depth, tail_stream)))
+        return rc;
+    return hipbm25_search_dev(bm25_h, term_ids_host, q_offsets_host, nq, depth, reinterpret_cast<double*>(pack_dev + leg),
+                              scratch_f32_dev + (size_t)nq * depth, pack_dev + leg + (size_t)nq * depth, tail_stream);
+}
+
+int32_t hiphybrid_shard_end_dev(const int64_t* gathered_dev, int32_t n_parts, int32_t nq, int32_t depth, int32_t k,
+                                int32_t dense_metric, float c, float w_dense, float w_sparse, int64_t* scratch_dev,
+                                float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    HR_REQUIRE(n_parts > 0 && nq > 0 && depth > 0 && k > 0, "bad hybrid shape");
+    HR_REQUIRE(gathered_dev && scratch_dev && out_scores_dev && out_ids_dev, "null argument");
+    const size_t nd = (size_t)nq * depth, part = 4 * nd;      // one rank's pack: 2 legs x {scores, ids} x nq x depth
+    int64_t* dl_s = scratch_dev;                              // merged dense leg: score bits | ids, then the sparse leg
+    int64_t* dl_i = scratch_dev + nd;
+    int64_t* sl_s = scratch_dev + 2 * nd;
+    int64_t* sl_i = scratch_dev + 3 * nd;
+    int32_t rc;
+    // each leg merged GLOBALLY with the canonical comparator, then RRF over the two global lists (ranks are global: fusing
+    // per shard and merging afterwards would be a different function)
+    if ((rc = hiprag_merge_topk_dev(reinterpret_cast<const double*>(gathered_dev), gathered_dev + nd, n_parts, nq, depth, depth,
+                                    (int64_t)part, dense_metric, reinterpret_cast<double*>(dl_s), nullptr, dl_i, stream)))
+        return rc;
+    if ((rc = hiprag_merge_topk_dev(reinterpret_cast<const double*>(gathered_dev + 2 * nd), gathered_dev + 3 * nd, n_parts, nq, depth,
+                                    depth, (int64_t)part, HIPRAG_METRIC_IP, reinterpret_cast<double*>(sl_s), nullptr, sl_i, stream)))
+        return rc;
+    return hiprrf_fuse_dev(dl_i, sl_i, nq, depth, depth, k, c, w_dense, w_sparse, out_scores_dev, out_ids_dev, stream);
 }
 
 int32_t hiprag_device_sync(int32_t device)

@@ -45,6 +45,10 @@ SIGNATURES = {
     "hiprag_shutdown": [],
     "hiphybrid_search": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float,
                          c_float, c_void_p, c_void_p],
+    "hiphybrid_shard_begin_dev": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p],
+    "hiphybrid_shard_end_dev": [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,
+                                c_void_p, c_void_p, c_void_p],
     "hiprag_event_create": [u64p],
     "hiprag_event_record": [c_uint64, c_void_p],
     "hiprag_probe_read_gbps": [c_int32, c_int64, c_int32, POINTER(c_double)],

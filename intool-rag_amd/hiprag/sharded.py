@@ -34,13 +34,12 @@ def chunks_of_rank(n_chunks: int, world: int, rank: int) -> List[int]:
 
 
 def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
-    """The ONE collective of a sharded search: every rank contributes `pack` ([2, nq, k] int64 = fp64 score bits and
-    ids) and receives `gathered` ([world, 2, nq, k]).  RCCL ("nccl") gathers into the tensor directly; other backends
-    (gloo in the CPU tests) take the list form over the same memory."""
+    """The ONE collective of a sharded search: every rank contributes `pack` (int64: fp64 score bits and ids of its partial
+    lists) and receives `gathered` ([world, *pack.shape]) -- one RCCL all_gather_into_tensor over xGMI.  Hosts and tests
+    with another transport (the two-ranks-on-one-GPU rehearsals over gloo) pass their own callable with this signature as
+    the `gather` argument of the sharded classes."""
     import torch.distributed as dist
-    if dist.get_backend(group) == "nccl":
-        return dist.all_gather_into_tensor(gathered, pack, group=group, async_op=async_op)
-    return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
+    return dist.all_gather_into_tensor(gathered, pack, group=group, async_op=async_op)
 
 
 def _slot_streams(device):
@@ -83,11 +82,12 @@ def check_same_shape(shape: tuple, group=None) -> None:
 
 
 class ShardedFlatIndex:
-    def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None):
+    def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None, gather=None):
         import torch
         import torch.distributed as dist
         self.local = local
         self.group = group
+        self.gather = gather or all_gather_packed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # the exchange (one all-gather per batch + merge) runs whenever there is more than one rank;
@@ -184,7 +184,7 @@ class ShardedFlatIndex:
         work = None
         if self.exchange:
             with torch.cuda.stream(side):
-                work = all_gather_packed(pack, c["gathered"], self.group, async_op=True)
+                work = self.gather(pack, c["gathered"], self.group, async_op=True)
         return (work, slot, k)
 
     def search_end(self, ticket, wait: bool = True):
@@ -286,15 +286,17 @@ def _merge_and_fuse(gathered, depth: int, k: int, metric, c: float, w_dense: flo
 
 
 class ShardedHybrid:
-    """Row-sharded hybrid search with the same pipeline as ShardedFlatIndex: the dense scan of a batch is enqueued on the
-    caller's stream; its finish, the BM25 leg, the ONE all-gather of both packed partial lists (async) and -- in
-    search_end -- the two global merges and the fusion run on the stream of one of eight slots, on pre-allocated
-    per-slot buffers.  Batches larger than the agreed launch size are cut into pipelined pieces."""
+    """Row-sharded hybrid search with the same pipeline as ShardedFlatIndex, as a client of the C-ABI's two halves
+    (hiphybrid_shard_begin_dev / hiphybrid_shard_end_dev, include/hiprag.h): `search_begin` = one library call -- the dense
+    scan of the batch on the caller's stream; its finish and the BM25 leg on the stream of one of eight slots, filling the
+    two halves of ONE packed buffer -- then the ONE all-gather (async) on that stream; `search_end` = one library call:
+    the two global merges and the fusion.  Pre-allocated per-slot buffers; batches larger than the agreed launch size are
+    cut into pipelined pieces."""
 
-    def __init__(self, dense: HipFlatIndex, bm25, row_lo: int = 0, group=None):
-        import torch
+    def __init__(self, dense: HipFlatIndex, bm25, row_lo: int = 0, group=None, gather=None):
         import torch.distributed as dist
         self.dense, self.bm25, self.group = dense, bm25, group
+        self.gather = gather or all_gather_packed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.exchange = _exchange_on(self.world)     # see ShardedFlatIndex
         dense.set_id_base(row_lo)
@@ -327,19 +329,19 @@ class ShardedHybrid:
             c["s32"] = torch.empty((2, nq, depth), dtype=torch.float32, device=dev)
             c["gathered"] = (torch.empty((self.world, 2, 2, nq, depth), dtype=torch.int64, device=dev)
                              if self.exchange else None)
-            c["legs"] = [(torch.empty((nq, depth), dtype=torch.float64, device=dev),
-                          torch.empty((nq, depth), dtype=torch.float32, device=dev),
-                          torch.empty((nq, depth), dtype=torch.int64, device=dev)) for _ in range(2)]
+            c["merged"] = torch.empty((4, nq, depth), dtype=torch.int64, device=dev)       # scratch of hiphybrid_shard_end_dev
             c["fused"] = (torch.empty((nq, k), dtype=torch.float32, device=dev),
                           torch.empty((nq, k), dtype=torch.int64, device=dev))
-            c["scanned"], c["fin"] = torch.cuda.Event(), torch.cuda.Event()
+            c["fin"] = torch.cuda.Event()
         return c
 
     def search_begin(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
                      w_sparse: float = 1.0):
         """q: float32 CUDA tensor [nq <= max_pass, d], the same on every rank, valid until search_end; sparse_queries: nq
         term-id lists.  Returns a ticket; the tensors search_end hands out belong to the slot (reused 8 batches later)."""
+        import ctypes
         import torch
+        from . import _native as nat
         nq = q.shape[0]
         if nq > self.max_pass or len(sparse_queries) != nq:
             raise ValueError(f"search_begin takes at most {self.max_pass} queries with one term list each")
@@ -351,39 +353,38 @@ class ShardedHybrid:
         side, pack = self.side[slot], b["pack"]
         if self._used[slot] and not self._ended[slot]:
             main.wait_event(b["fin"])
-        self.dense.search_begin(q, depth, slot, stream=main.cuda_stream)        # the HBM-heavy part: scans stay chained
-        b["scanned"].record(main)
-        side.wait_event(b["scanned"])
+        terms, qoff = self.bm25._flatten(sparse_queries)
+        nat.call("hiphybrid_shard_begin_dev", self.dense._h, self.bm25._h, q.data_ptr(), terms.ctypes.data if terms.size else None,
+                 qoff.ctypes.data, nq, int(depth), slot, pack.data_ptr(), b["s32"].data_ptr(), ctypes.c_void_p(main.cuda_stream),
+                 ctypes.c_void_p(self._side_ptr[slot]))
         self._used[slot], self._ended[slot] = True, False
-        self.dense.search_finish(q, depth, slot, (pack[0, 0].view(torch.float64), b["s32"][0], pack[0, 1]),
-                                 stream=self._side_ptr[slot])
         work = None
-        with torch.cuda.stream(side):
-            self.bm25.search_device(sparse_queries, depth, out=(pack[1, 0].view(torch.float64), b["s32"][1], pack[1, 1]))
-            if self.exchange:
-                work = all_gather_packed(pack, b["gathered"], self.group, async_op=True)
+        if self.exchange:
+            with torch.cuda.stream(side):
+                work = self.gather(pack, b["gathered"], self.group, async_op=True)
         return (work, slot, depth, k, c, w_dense, w_sparse)
 
     def search_end(self, ticket, wait: bool = True):
         """-> (fused scores float32 [nq,k], ids int64 [nq,k]), identical on every rank."""
+        import ctypes
         import torch
-        from ._native import METRIC_IP
-        from .fusion import rrf_fuse_device
+        from . import _native as nat
         work, slot, depth, k, c, w_dense, w_sparse = ticket
         b = self._bufs[slot]
         side = self.side[slot]
+        nq = b["pack"].shape[2]
         with torch.cuda.stream(side):
             if work is not None:
                 work.wait()
-            g = b["gathered"] if self.exchange else b["pack"].unsqueeze(0)
-            dl = merge_topk_device(g[:, 0, 0].view(torch.float64), g[:, 0, 1], depth, self.dense.metric, out=b["legs"][0])
-            sl = merge_topk_device(g[:, 1, 0].view(torch.float64), g[:, 1, 1], depth, METRIC_IP, out=b["legs"][1])
-            out = rrf_fuse_device(dl[2], sl[2], k, c, w_dense, w_sparse, out=b["fused"])
+            g = b["gathered"] if self.exchange else b["pack"]
+            nat.call("hiphybrid_shard_end_dev", g.data_ptr(), self.world if self.exchange else 1, nq, int(depth), int(k),
+                     int(self.dense.metric), float(c), float(w_dense), float(w_sparse), b["merged"].data_ptr(),
+                     b["fused"][0].data_ptr(), b["fused"][1].data_ptr(), ctypes.c_void_p(self._side_ptr[slot]))
             b["fin"].record(side)
         self._ended[slot] = wait
         if wait:
             torch.cuda.current_stream().wait_event(b["fin"])
-        return out
+        return b["fused"]
 
     def search_device(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
                       w_sparse: float = 1.0):

@@ -20,6 +20,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def list_gather(pack, gathered, group=None, async_op=True):
+    """The exchange over a backend without all_gather_into_tensor (gloo: the CPU protocol test and the two-ranks-on-one-GPU
+    rehearsals) -- same memory, list form.  The product's gather is RCCL's all_gather_into_tensor (hiprag/sharded.py)."""
+    import torch.distributed as dist
+    return dist.all_gather([gathered[r] for r in range(gathered.shape[0])], pack, group=group, async_op=async_op)
+
+
 def _setup(rank, world, port):
     for p in (REPO, os.path.join(REPO, "intool-rag_amd")):
         if p not in sys.path:
@@ -33,7 +40,7 @@ def _setup(rank, world, port):
 def _cpu_worker(rank, world, port, q_out):
     import torch
     dist = _setup(rank, world, port)
-    from hiprag.sharded import all_gather_packed, chunks_of_rank, shard_bounds
+    from hiprag.sharded import chunks_of_rank, shard_bounds
     from oracle import hybrid_oracle as ho
     try:
         n, d, nq, k = 4001, 48, 6, 10
@@ -46,7 +53,7 @@ def _cpu_worker(rank, world, port, q_out):
             pack[0] = torch.from_numpy(s64.view(np.int64))
             pack[1] = torch.from_numpy(ids)
             gathered = torch.empty((world, 2, nq, k), dtype=torch.int64)
-            all_gather_packed(pack, gathered, None, async_op=True).wait()
+            list_gather(pack, gathered, None, async_op=True).wait()
             parts_s = [gathered[r, 0].numpy().view(np.float64) for r in range(world)]
             parts_i = [gathered[r, 1].numpy() for r in range(world)]
             ms, mi = ho.merge_partial_topk(parts_s, parts_i, k, metric)
@@ -68,7 +75,7 @@ def _cpu_worker(rank, world, port, q_out):
         pack[1, 0] = torch.from_numpy(bs.astype(np.float64).view(np.int64))
         pack[1, 1] = torch.from_numpy(bids)
         gathered = torch.empty((world,) + tuple(pack.shape), dtype=torch.int64)
-        all_gather_packed(pack, gathered, None, async_op=True).wait()
+        list_gather(pack, gathered, None, async_op=True).wait()
         g = gathered.numpy()
         _, gd = ho.merge_partial_topk([g[r, 0, 0].view(np.float64) for r in range(world)], [g[r, 0, 1] for r in range(world)],
                                       depth, ho.METRIC_IP)
@@ -142,7 +149,7 @@ def _gpu_worker(rank, world, port, q_out):
         for metric in ("ip", "l2"):
             local = HipFlatIndex(d, metric)
             local.add(x[lo:hi])
-            sh = ShardedFlatIndex(local, lo)
+            sh = ShardedFlatIndex(local, lo, gather=list_gather)
             assert sh.world == world
             s64, s32, ids = sh.search_device(torch.from_numpy(q).cuda(), k)
             torch.cuda.synchronize()
@@ -182,7 +189,7 @@ def _gpu_hybrid_worker(rank, world, port, q_out):
         local = HipFlatIndex(d, "ip")
         local.add(x[lo:hi])
         full = PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts)
-        sh = ShardedHybrid(local, HipBM25(full.shard(lo, hi)), lo)
+        sh = ShardedHybrid(local, HipBM25(full.shard(lo, hi)), lo, gather=list_gather)
         assert sh.world == world and sh.max_pass == 64
         qd = torch.from_numpy(q).cuda()
         _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
