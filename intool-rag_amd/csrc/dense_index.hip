@@ -185,20 +185,23 @@ __global__ void retile_bf16_kernel(const float* __restrict__ src, int64_t row0, 
 // Rounds 1-2 wrote both for EVERY group (N/16 floats x 2 per query: 256 MB per 512-query launch at 1M rows) and a
 // selector read them back to keep a few dozen -- 1.6 % of the launch's bytes and 7-20 % of its time, depending on where the
 // buffers had landed.  Now the scan keeps the few that matter itself:
-//   * every wave PUBLISHES the maximum `first` of each kPublish-block chunk it finishes, per query, with one atomicMax
-//     into one of 64 class slots of that query (class = global wave index mod 64; one coalesced 256-byte atomic per wave
-//     and chunk).  theta(query) = min over the 64 slots: 64 distinct groups reach it, and on average ~4.5 x 64 groups of the
-//     whole index do.  One wave per workgroup and chunk (they take turns) recomputes theta and raises thetac[query].
-//   * a group's values stay in registers (shift chains) for kAge more blocks and are then tested against the CURRENT
-//     thetac of their query: first >= thetac -> appended to the query's CANDIDATE LIST (packed first | group id, second),
-//     else dropped.  thetac only ever rises, so every group with first >= the final thetac is on the list, whatever the
-//     timing: a late publisher only makes the lists longer, never wrong.
-//   * appends go to a small LDS staging list (LDS atomics return on lgkmcnt: the hand-counted vmcnt ring never sees them)
-//     and reach the per-query global lists in the pass prologues, one global atomicAdd per entry (~600 entries per
-//     query at 1M rows, 5 MB per launch instead of 256).
-// The finish (fin_kernel) ranks a query's list, re-scores its best groups in fp64 and extends the re-scored prefix until
-// nothing on the list can still reach the top k; everything NOT on the list has first < final thetac, which the certificate
-// takes as the bound of the unseen rows.
+//   * PUBLISH.  Every wave publishes the maximum `first` of each chunk it finishes (after the first block of its range, then
+//     every kPublish blocks), per query, with one atomicMax into one of 64 class slots of that query (class = a mix of wave
+//     and workgroup index, so that every class has members on every XCD and in every wave slot; one coalesced 256-byte
+//     memory-side atomic per wave and chunk).
+//   * BOUND.  theta(query) = min over the class slots: 64 distinct groups reach it, and on average ~4.5 x 64 groups of the
+//     whole index do.  The waves of a workgroup take turns recomputing it, kRecompute blocks behind a publish; the result
+//     goes into thetac[query] (global, atomicMax: it only ever rises) and into the workgroup's LDS copy.
+//   * TEST.  A group's values stay in registers (shift chains) for kAge more blocks and are then tested against the LDS
+//     copy of their query's bound: first >= bound -> staged in LDS (LDS atomics return on lgkmcnt: the hand-counted vmcnt
+//     ring never sees them), else dropped.  A wave that gets there before the bound of the pass exists waits for it (bounded).
+//   * FLUSH.  In the pass prologues (and at the end) the staged entries are tested again, against bounds refreshed
+//     memory-side, and appended to the per-query CANDIDATE LISTS in global memory, one global atomicAdd per entry: ~350
+//     entries per query at 1M rows, 3 MB per launch instead of 256.
+// Exactness never depends on timing: every value that was dropped was below a bound that had been folded into thetac, so
+// the FINAL thetac[q] bounds everything that is not on q's list -- a late publisher makes lists longer, never wrong.  The
+// finish (fin_kernel) ranks a query's list, re-scores its best groups in fp64 and extends the re-scored prefix until nothing
+// on the list can still reach the top k; the certificate takes the final thetac as the bound of the unseen rows.
 constexpr int kClasses = 64;      // theta slots per query
 constexpr int kCandCap = 4096;    // candidate-list entries per query in global memory (overflow -> exhaustive path)
 constexpr int kPublish = 4;       // blocks per published chunk
@@ -223,13 +226,11 @@ struct ScanArgs {
     u32* thetac;          // [Q] current bound per query (ord32 image; 0 = none yet)
     u32* count;           // [Q] appended candidates per query
     Cand* list;           // [Q][kCandCap]
-    u32* arrive;          // waves that have published their last chunk (end-of-launch rendezvous, bounded wait)
     int64_t nblocks;
     int64_t ntotal;
     int nq, d, P;
     int filter;           // 0: list every group (small indexes)
-    int n_active;         // waves that own blocks
-    int ncls;             // theta classes in use: min(kClasses, n_active) -- every class must have a publisher, or theta never forms
+    int ncls;             // theta classes in use: min(kClasses, waves that own blocks) -- every class needs a publisher, or theta never forms
     unsigned long long* stamps;  // timing only (else null): [waves][2] wall-clock ticks at wave entry / exit
 };
 
@@ -999,7 +1000,6 @@ struct FinArgs {
     u32* thetac;
     u32* count;
     const Cand* list;
-    u32* arrive;
     int64_t ntotal, id_base;
     int d, P, k, mode, filter;
 };
@@ -1320,7 +1320,7 @@ struct DenseIndex {
                                 // [2..3] fallback counter (u64), [4..5] extended-prefix counter
     // search workspace of one launch in flight
     struct Workspace {
-        DevBuf list, state, flags, ek, ei;   // state: count[Q] | thetac[Q] | arrive[16] | slots[Q / 64][kClasses][64]
+        DevBuf list, state, flags, ek, ei;   // state: count[Q] | thetac[Q] | slots[Q / 64][kClasses][64]
         int k = 0, q = 0;
         int64_t blocks = 0;
         int ev_idx = -1;
@@ -1519,11 +1519,10 @@ struct DenseIndex {
         w.q = (int)Q;
         return HIPRAG_OK;
     }
-    static size_t state_words(size_t Q) { return 2 * Q + 16 + (Q / 64) * kClasses * 64; }
+    static size_t state_words(size_t Q) { return 2 * Q + (Q / 64) * kClasses * 64; }
     static u32* st_count(const Workspace& w) { return w.state.as<u32>(); }
     static u32* st_thetac(const Workspace& w) { return w.state.as<u32>() + w.q; }
-    static u32* st_arrive(const Workspace& w) { return w.state.as<u32>() + 2 * (size_t)w.q; }
-    static u32* st_slots(const Workspace& w) { return w.state.as<u32>() + 2 * (size_t)w.q + 16; }
+    static u32* st_slots(const Workspace& w) { return w.state.as<u32>() + 2 * (size_t)w.q; }
 
     // phase 1 of a launch (<= launch_q queries): the scan, into workspace `slot`
     template <int METRIC>
@@ -1543,13 +1542,12 @@ struct DenseIndex {
             w.waves = nw;
             ScanArgs sa;
             sa.xb = xb.as<float4>(); sa.xh = xh.p; sa.q = q_dev; sa.norms = norms.as<float>();
-            sa.slots = st_slots(w); sa.thetac = st_thetac(w); sa.count = st_count(w); sa.arrive = st_arrive(w);
+            sa.slots = st_slots(w); sa.thetac = st_thetac(w); sa.count = st_count(w);
             sa.list = w.list.as<Cand>();
             sa.nblocks = nb; sa.ntotal = ntotal; sa.nq = nq; sa.d = d; sa.P = P;
             sa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
             const int64_t bpw = scan_blocks_per_wave(nb, (int64_t)scan_cus * nw);
-            sa.n_active = (int)((nb + bpw - 1) / bpw);
-            sa.ncls = std::max(1, std::min(kClasses, sa.n_active));
+            sa.ncls = (int)std::max<int64_t>(1, std::min<int64_t>(kClasses, (nb + bpw - 1) / bpw));   // waves that own blocks
             if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2, 0, (size_t)scan_cus * kMaxScanWaves * 16, st));
             sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2 : nullptr;
             const size_t scan_lds = (size_t)P * 1024 + (size_t)kStageCap * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
@@ -1591,7 +1589,7 @@ struct DenseIndex {
             fa.xb = xb.as<float4>(); fa.q = q_dev; fa.max_norm2_bits = max_norm2_bits();
             fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp; fa.flags = flags; fa.arrivals = arrivals;
             fa.fallback_counter = fallback_counter(); fa.extend_counter = extend_counter(); fa.work_counters = work_counters();
-            fa.slots = st_slots(w); fa.thetac = st_thetac(w); fa.count = st_count(w); fa.arrive = st_arrive(w);
+            fa.slots = st_slots(w); fa.thetac = st_thetac(w); fa.count = st_count(w);
             fa.list = w.list.as<Cand>();
             fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.mode = scan_mode;
             fa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
@@ -1860,20 +1858,6 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
     if (rc) return rc;
     HR_CHECK_HIP(hipMemcpy(out_scores, ix->o32.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     HR_CHECK_HIP(hipMemcpy(out_ids, ix->oid.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
-    return HIPRAG_OK;
-}
-
-// DEBUG (not in the header): the scan state of a slot after a begin without its finish -- count[Q], thetac[Q], slots[Q/64][64][64]
-int32_t hipidx_debug_scan_state(uint64_t h, int32_t slot, uint32_t* out_count, uint32_t* out_thetac, uint32_t* out_slots, int32_t* out_q, uint32_t* out_arrive)
-{
-    GET_INDEX(h);
-    HR_CHECK_HIP(hipDeviceSynchronize());
-    DenseIndex::Workspace& w = ix->ws[slot];
-    *out_q = w.q;
-    HR_CHECK_HIP(hipMemcpy(out_count, DenseIndex::st_count(w), (size_t)w.q * 4, hipMemcpyDeviceToHost));
-    HR_CHECK_HIP(hipMemcpy(out_thetac, DenseIndex::st_thetac(w), (size_t)w.q * 4, hipMemcpyDeviceToHost));
-    HR_CHECK_HIP(hipMemcpy(out_arrive, DenseIndex::st_arrive(w), 64, hipMemcpyDeviceToHost));
-    HR_CHECK_HIP(hipMemcpy(out_slots, DenseIndex::st_slots(w), (size_t)(w.q / 64) * 4096 * 4, hipMemcpyDeviceToHost));
     return HIPRAG_OK;
 }
 

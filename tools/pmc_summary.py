@@ -15,7 +15,7 @@ def collect(d, counter):
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 alg = int(sys.argv[4])
 fb, wb = fetch["mean_kb"] * 1024 * 2, write["mean_kb"] * 1024
-out = {"kernel": "scan_bf16_kernel<IP, 8 waves, ring 16, multi-pass>, 8 passes per launch",
+out = {"kernel": "scan_bf16_kernel<IP, 8 waves, ring 16, multi-pass>, 8 passes per launch (round 3: candidate lists kept by the scan itself)",
        "workload": "1M x 1024 rows (bf16 filter copy, 2.048 GB), 512 queries per launch (tools/seq_search.py: sequential hipidx_search_dev)",
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/seq_search.py",
                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/seq_search.py"],

@@ -20,4 +20,4 @@ for nq in (64, 512):
     for i in range(10): ix.search_device(q[i * 64:i * 64 + nq], 10)
     torch.cuda.synchronize()
     st = ix.stats(); ix.enable_timing(False)
-    print(f"tail={os.environ.get('HIPRAG_DEBUG_TAIL','0'):>3} nq {nq:4d}: scan {st['avg_scan_ms']:.3f} ms (gpu clock {st['avg_scan_wall_ms']:.3f})", flush=True)
+    print(f"nq {nq:4d}: scan {st['avg_scan_ms']:.3f} ms (gpu clock {st['avg_scan_wall_ms']:.3f})", flush=True)
