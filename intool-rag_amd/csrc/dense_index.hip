@@ -1409,10 +1409,16 @@ struct DenseIndex {
         void* nx = nullptr;
         void* nn = nullptr;
         void* nh = nullptr;
-        HR_CHECK_HIP(hipMalloc(&nx, xbytes));
-        hipError_t e = hipMalloc(&nn, nbytes);
-        if (e == hipSuccess) e = hipMalloc(&nh, hbytes);
-        if (e != hipSuccess) { (void)hipFree(nx); if (nn) (void)hipFree(nn); HR_CHECK_HIP(e); }
+        // The buffer the scan STREAMS is allocated first.  How fast 2048 waves stream a buffer depends on which physical pages
+        // it got: the same binary scanned 1M rows at 2.77-2.94 ms per launch with the filter copy allocated behind the 4 GB
+        // of fp32 rows and at 2.60-2.66 with it allocated first (A/B in fresh processes, several boxes; the "allocation
+        // lottery" of rounds 1-2, which blamed the scan's output).  Probing several candidate allocations and keeping the
+        // fastest was measured too and bought nothing beyond this order.
+        const bool stream_h = scan_mode == 3;
+        HR_CHECK_HIP(hipMalloc(stream_h ? &nh : &nx, stream_h ? hbytes : xbytes));
+        hipError_t e = hipMalloc(stream_h ? &nx : &nh, stream_h ? xbytes : hbytes);
+        if (e == hipSuccess) e = hipMalloc(&nn, nbytes);
+        if (e != hipSuccess) { if (nx) (void)hipFree(nx); if (nh) (void)hipFree(nh); if (nn) (void)hipFree(nn); HR_CHECK_HIP(e); }
         HR_CHECK_HIP(hipMemset(nx, 0, xbytes));
         HR_CHECK_HIP(hipMemset(nn, 0, nbytes));
         HR_CHECK_HIP(hipMemset(nh, 0, hbytes));

@@ -7,11 +7,15 @@ comparator is (score, id), the sharded result equals the unsharded one bit for b
 
 The reference is a single CPU process: this is new capability, not a port of anything.
 
-Pipelining.  The index scan is the only HBM-heavy stage; selection, re-scoring, the exchange and the merge are
-latency-bound.  `search_begin` therefore enqueues the scan (one launch of up to `launch_queries` queries = several
-passes over the local rows) on the caller's stream and everything after it on the stream of one of eight workspace
-slots, so that the tails of earlier batches run beside later scans -- on the CUs the scan grid leaves free.
-`search_end` enqueues the merge of the gathered partial lists and makes the caller's stream wait for the result.
+Pipelining.  The index scan is the only HBM-heavy stage; the finish, the exchange and the merge are latency-bound.
+With an exchange (N > 1) `search_begin` enqueues the scan (one launch of up to `launch_queries` queries = several passes over
+the local rows) on the caller's stream and everything after it on the stream of one of eight workspace slots, so that the
+exchange of earlier batches -- whose all-gather waits for the slowest rank -- runs beside later scans, on the CUs the scan
+grid leaves free; `search_end` enqueues the merge of the gathered partial lists and makes the caller's stream wait for it.
+WITHOUT an exchange (one GPU) the finish follows its scan on the caller's stream: a scan workgroup takes its CU's whole LDS,
+so a finish that is released together with the next scan either holds CUs that scan is statically partitioned over (its
+workgroups there start late and the launch ends late: measured 2.68-2.87 ms per launch against 2.49 alone) or waits for
+the scan after it; in stream order the finish costs its own 0.08 ms and nothing else (2.57 ms per 512-query step, 1M rows).
 """
 from __future__ import annotations
 
@@ -82,7 +86,9 @@ def check_same_shape(shape: tuple, group=None) -> None:
 
 
 class ShardedFlatIndex:
-    def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None, gather=None):
+    def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None, gather=None, tails_aside=None):
+        """tails_aside: None = the finish runs beside later scans (slot streams) exactly when there is an exchange to overlap
+        with, in stream order otherwise (module docstring); True / False force one arrangement (tests, A/B measurements)."""
         import torch
         import torch.distributed as dist
         self.local = local
@@ -93,6 +99,7 @@ class ShardedFlatIndex:
         # the exchange (one all-gather per batch + merge) runs whenever there is more than one rank;
         # HIPRAG_FORCE_EXCHANGE=1 runs it on a one-rank group as well (a single-GPU box can then exercise the RCCL calls)
         self.exchange = _exchange_on(self.world)
+        self.tails_aside = self.exchange if tails_aside is None else bool(tails_aside) or self.exchange
         local.set_id_base(row_lo)
         if self.exchange:
             # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
@@ -127,8 +134,10 @@ class ShardedFlatIndex:
         key = (nq, k)
         cache = self._bufs[slot]
         if cache.get("key") != key:
-            if self._slot_used[slot]:
-                self.side[slot].synchronize()     # kernels of the slot's previous shape may still read the old buffers
+            if self._slot_used[slot]:             # kernels of the slot's previous shape may still read the old buffers
+                self.side[slot].synchronize()
+                if not self.tails_aside:
+                    torch.cuda.current_stream().synchronize()
             cache.clear()
             cache["key"] = key
             cache["pack"] = torch.empty((2, nq, k), dtype=torch.int64, device=dev)
@@ -155,28 +164,23 @@ class ShardedFlatIndex:
         c = self._buffers(slot, nq, k, q.device)
         # Scans are chained on the caller's stream (one after the other, so a scan never shares the CUs with another
         # scan and HIP events around a launch measure that launch); everything after the scan runs on the slot's own
-        # stream beside the next scans.  A scan launch runs several passes back to back, which amortises the ~40 us
-        # dependent-dispatch bubble between chained launches.  HIPRAG_SCAN_STREAMS=side moves the scans to the slot
-        # streams too (scan i released when scan i-2 completes): ~1 % (1M rows) to 3 % (125k-row shard) more throughput,
-        # but consecutive scans then overlap at their ragged ends and per-launch event times include queueing.
+        # stream beside the next scans.
         side = self.side[slot]
         pack = c["pack"]
-        if os.environ.get("HIPRAG_SCAN_STREAMS") != "side":
-            if self._slot_used[slot] and not self._slot_ended[slot]:
-                # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
-                # waited there and stream order covers it (one barrier packet less per step)
-                main.wait_event(c["fin"] if self.exchange else c["done"])
+        if not self.tails_aside:
+            # one GPU, nothing to overlap with: scan and finish in stream order on the caller's stream (module docstring)
             self.local.search_begin(q, k, slot, stream=main.cuda_stream)
-            c["scanned"].record(main)
-            side.wait_event(c["scanned"])
-        else:
-            c["scanned"].record(main)          # q was produced on the caller's stream
-            side.wait_event(c["scanned"])
-            before = (slot - 2) % N_SLOTS
-            if self._slot_used[before]:
-                side.wait_event(self._scan_done[before])
-            self.local.search_begin(q, k, slot, stream=self._side_ptr[slot])
-            self._scan_done[slot].record(side)
+            self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=main.cuda_stream)
+            self._slot_used[slot] = True
+            self._slot_ended[slot] = True
+            return (None, slot, k)
+        if self._slot_used[slot] and not self._slot_ended[slot]:
+            # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
+            # waited there and stream order covers it (one barrier packet less per step)
+            main.wait_event(c["fin"] if self.exchange else c["done"])
+        self.local.search_begin(q, k, slot, stream=main.cuda_stream)
+        c["scanned"].record(main)
+        side.wait_event(c["scanned"])
         self._slot_used[slot] = True
         self._slot_ended[slot] = False
         self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=self._side_ptr[slot])
@@ -195,10 +199,12 @@ class ShardedFlatIndex:
         work, slot, k = ticket
         c = self._bufs[slot]
         main = torch.cuda.current_stream()
-        self._slot_ended[slot] = wait
+        self._slot_ended[slot] = wait or not self.tails_aside
         if work is None:
-            if wait:
-                main.wait_event(c["done"])
+            if self.tails_aside:
+                if wait:
+                    main.wait_event(c["done"])
+            # else: the results are in stream order on the stream search_begin was called on
             return (c["pack"][0].view(torch.float64), c["s32"], c["pack"][1])
         side = self.side[slot]
         with torch.cuda.stream(side):
@@ -213,6 +219,11 @@ class ShardedFlatIndex:
     def result_event(self, ticket):
         """Event that completes when the results of `ticket` are final (after search_end)."""
         work, slot, _ = ticket
+        if work is None and not self.tails_aside:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return ev
         return self._bufs[slot]["fin" if work is not None else "done"]
 
     def search_device(self, q, k: int):

@@ -426,22 +426,21 @@ def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
             raise AssertionError(f"case {case}: n={n} d={d} k={k} nq={nq} metric={metric} mode={mode}: {e}")
 
 
-@pytest.mark.parametrize("streams", ["main", "side"])
-def test_deep_pipeline_with_changing_batch_shapes(gpu, monkeypatch, streams):
+@pytest.mark.parametrize("tails", ["in_stream_order", "aside"])
+def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
     """Six launches in flight over the eight workspace slots, batch size and k changing from launch to launch (every slot's
-    buffers are re-shaped while older launches are still running), in both stream arrangements of the scans."""
+    buffers are re-shaped while older launches are still running), in both arrangements of the finish: behind its scan on the
+    caller's stream (one GPU) and on the slot streams beside later scans (what row-sharded serving does around its exchange)."""
     import torch
     from collections import deque
     from hiprag import HipFlatIndex
     from hiprag.sharded import ShardedFlatIndex
-    if streams == "side":
-        monkeypatch.setenv("HIPRAG_SCAN_STREAMS", "side")
     n, d = 20000, 256
     x = ho.synthetic_vectors(n, d, seed=71)
     q = ho.synthetic_queries(256, d, seed=72)
     ix = HipFlatIndex(d, "ip")
     ix.add(x)
-    sh = ShardedFlatIndex(ix, 0)
+    sh = ShardedFlatIndex(ix, 0, tails_aside=(tails == "aside"))
     qd = torch.from_numpy(q).cuda()
     rng = np.random.default_rng(5)
     plan = [(int(rng.choice([1, 17, 64, 65, 200, 256])), int(rng.choice([1, 10, 50]))) for _ in range(40)]

@@ -3,17 +3,28 @@ duration per kernel.  usage: pmc_hybrid_summary.py <pmc_dir> <out.json>"""
 import csv, glob, json, sys
 from collections import defaultdict
 
+TARGETS = ("scan_bf16_kernel", "scan_split_kernel", "fin_kernel", "taat_tile_kernel", "merge_packed_loop_kernel", "merge_packed_kernel",
+           "rrf_kernel", "exhaustive_kernel", "merge_wave_kernel")
+
+
+def short(name):
+    for t in TARGETS:
+        if t in name:
+            return t
+    return None
+
+
 d = sys.argv[1]
 f = glob.glob(d + "/*/*counter_collection.csv")[0]
 fetch = defaultdict(list)
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] == "FETCH_SIZE":
-        fetch[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        fetch[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
 dur = defaultdict(list)
 kt = glob.glob(d + "/*/*kernel_trace.csv")
 if kt:
     for r in csv.DictReader(open(kt[0])):
-        dur[r["Kernel_Name"].split("(")[0]].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+        dur[short(r["Kernel_Name"])].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/bench_hybrid.py",
        "workload": "configs[2]: 1M chunks, 148 M postings, 256 queries per launch, 6 terms per query (449,804 postings = 3.6 MB requested per query)",
        "note": "FETCH_SIZE in KiB per launch as reported; on gfx950 it reads half the bytes of wide (dwordx4) streaming loads "
@@ -21,7 +32,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv
                "established: its HBM traffic lies between the raw figure and twice that",
        "kernels": {}}
 for k, v in fetch.items():
-    if not any(t in k for t in ("scan_", "fin_kernel", "taat_", "merge_packed", "rrf", "exhaustive")):
+    if k is None:
         continue
     v2 = v[2:] if len(v) > 4 else v
     e = {"launches": len(v2), "fetch_kib_per_launch": round(sum(v2) / len(v2), 1)}
