@@ -208,7 +208,7 @@ constexpr int kPublish = 4;       // blocks per published chunk
 constexpr int kDelay = 4;         // blocks between the end of a value's chunk and its test (publishers of other workgroups catch up)
 constexpr int kAge = kPublish - 1 + kDelay;   // chain position at which a value is tested
 constexpr int kRecompute = 2;     // blocks between a chunk's publish and the recomputation of theta by the wave whose turn it is
-constexpr int kStageCap = 1792;   // staged appends per workgroup and pass (28 KiB of LDS); beyond that: direct global appends
+constexpr int kStageHalf = 896;   // staged appends per workgroup and pass (two alternating halves of 14 KiB of LDS); beyond that: direct global appends
 constexpr int kNoFilterGroups = 1024;   // indexes with at most this many groups list every group (= the finish's LDS list)
 
 struct Cand {       // one candidate group of one query, 16 bytes: staging entry and global list entry
@@ -283,7 +283,10 @@ __device__ __forceinline__ float block_lane_top2(const f32x16& acc, const f32x4 
 }
 
 // ---- the in-register / in-LDS tail of both scan kernels --------------------------------------------------------------
-// LDS behind the query tile: Cand stage[kStageCap] | u32 ctl[16] (ctl[0] = staged entries, ctl[4 + s] = tag of bound slot s)
+// LDS behind the query tile: Cand stage[2][kStageHalf] (the passes alternate between the halves: the appends of pass p go to
+// half p & 1 and are flushed in the prologue of pass p + 1, beside the staging of that pass's query tile) | u32 ctl[16] (ctl[h] =
+// appends into half h since the launch began -- never reset, every thread remembers what has been flushed; ctl[4 + s] = tag of
+// bound slot s)
 // | u32 bound[kThetaBack][64] -- the workgroup's copy of the bounds of the last kThetaBack passes (slot = pass & 7, tag =
 // pass + 1), which is what the in-loop test reads: NO global load sits in the block loop.  (A per-block global read of
 // thetac did, at first: those lines are rewritten memory-side all the time, so the read misses L2, and because loads return
@@ -301,13 +304,16 @@ struct ScanTail {
     int pa, ja;                               // pass and block offset of the value that is tested next
     int ev;                                   // publish events so far (the waves of a workgroup take turns recomputing theta)
     int rc_due, rc_pass;                      // pending recomputation of theta: when (in blocks of this wave) and for which pass
+    u32 flushed0, flushed1;                   // appends of each stage half that have been flushed (the same in every thread;
+                                              // two scalars, not an array: a dynamically indexed array would live in scratch memory,
+                                              // whose accesses count in vmcnt and drained the load ring -- 2.6 -> 3.5 ms per launch)
 
     __device__ __forceinline__ void init()
     {
 #pragma unroll
         for (int i = 0; i <= kAge; ++i) { cf[0][i] = cf[1][i] = -FLT_MAX; cs[0][i] = cs[1][i] = -FLT_MAX; }
         pm0 = pm1 = -INFINITY;
-        t = 0; pa = 0; ja = 0; ev = 0; rc_due = -1; rc_pass = 0;
+        t = 0; pa = 0; ja = 0; ev = 0; rc_due = -1; rc_pass = 0; flushed0 = flushed1 = 0;
     }
 };
 
@@ -392,15 +398,15 @@ __device__ __forceinline__ void append_direct(const ScanArgs& a, u64 key, float 
     if (p < (u32)kCandCap) a.list[(size_t)q * kCandCap + p] = Cand{key, sec, q};
 }
 
-__device__ __forceinline__ void stage_append(const ScanArgs& a, const TailLds& L, u64 key, float sec, u32 q)
+__device__ __forceinline__ void stage_append(const ScanArgs& a, const TailLds& L, int half, u32 flushed, u64 key, float sec, u32 q)
 {
-    const u32 p = atomicAdd(L.ctl, 1u);      // LDS atomic: returns on lgkmcnt, the hand-counted vmcnt ring never sees it
-    if (p < (u32)kStageCap) L.stage[p] = Cand{key, sec, q};
+    const u32 p = atomicAdd(L.ctl + half, 1u) - flushed;      // LDS atomic: returns on lgkmcnt, the hand-counted vmcnt ring never sees it
+    if (p < (u32)kStageHalf) L.stage[half * kStageHalf + p] = Cand{key, sec, q};
     else append_direct(a, key, sec, q);
 }
 
 // test one parked value pair (block b0 + T.ja of pass T.pa) against the bounds th0 / th1 of its two queries; advance (pa, ja)
-__device__ __forceinline__ void test_aged(const ScanArgs& a, ScanTail& T, const TailLds& L, float f0, float s0, float f1, float s1,
+__device__ __forceinline__ void test_aged(const ScanArgs& a, ScanTail& T, const TailLds& L, int half, float f0, float s0, float f1, float s1,
                                           u32 th0, u32 th1, int lane, int64_t b0, int nbw)
 {
     const int b = lane & 31, h = lane >> 5;
@@ -409,8 +415,9 @@ __device__ __forceinline__ void test_aged(const ScanArgs& a, ScanTail& T, const 
     const bool p1 = q1 < a.nq && ord32(f1) >= th1;
     if (__ballot(p0 || p1)) {   // wave-uniform: most blocks append nothing
         const u32 gid = (u32)(2 * (b0 + T.ja) + h);
-        if (p0) stage_append(a, L, pack_key(f0, gid), s0, (u32)q0);
-        if (p1) stage_append(a, L, pack_key(f1, gid), s1, (u32)q1);
+        const u32 fl = half ? T.flushed1 : T.flushed0;
+        if (p0) stage_append(a, L, half, fl, pack_key(f0, gid), s0, (u32)q0);
+        if (p1) stage_append(a, L, half, fl, pack_key(f1, gid), s1, (u32)q1);
     }
     if (++T.ja == nbw) { T.ja = 0; ++T.pa; }
 }
@@ -443,7 +450,7 @@ __device__ __forceinline__ void tail_block(const ScanArgs& a, ScanTail& T, const
                 th1 = lds_get_bound(L, T.pa, 32 + b);
             }
         }
-        test_aged(a, T, L, T.cf[0][kAge], T.cs[0][kAge], T.cf[1][kAge], T.cs[1][kAge], th0, th1, lane, b0, nbw);
+        test_aged(a, T, L, pass & 1, T.cf[0][kAge], T.cs[0][kAge], T.cf[1][kAge], T.cs[1][kAge], th0, th1, lane, b0, nbw);
     }
     if (T.rc_due >= 0 && T.t >= T.rc_due) { recompute_theta<false>(a, L, T.rc_pass, lane); T.rc_due = -1; }
     ++T.t;
@@ -460,23 +467,43 @@ __device__ __forceinline__ void refresh_bounds(const ScanArgs& a, const TailLds&
         if (p >= 0) lds_put_bound(L, p, lane, load_memside_u32(a.thetac + p * 64 + lane));
     }
 }
-// staged appends -> the queries' global lists (whole workgroup, between barriers).  Every entry is tested AGAIN, against
-// what its query's bound has become since it was staged: the in-loop test runs a few blocks behind the publishers, when
-// the bound of a pass is still forming (a wave that runs ahead tests against the publishes of the other fast waves only --
-// measured 0.6-1.1 k staged entries per query at 1M rows where the final bound admits 0.3 k); the flush runs a pass later,
-// or at the end of the launch.
+// staged appends of one half -> the queries' global lists (whole workgroup; the half is not appended to meanwhile).  Every
+// entry is tested AGAIN, against what its query's bound has become since it was staged: the in-loop test runs a few blocks
+// behind the publishers, when the bound of a pass is still forming (a wave that runs ahead tests against the publishes of the
+// other fast waves only -- measured 0.6-1.1 k staged entries per query at 1M rows where the final bound admits 0.3 k); the
+// flush runs a pass later, or at the end of the launch.  Two phases, so that the round trip of the list counters' atomics
+// hides behind whatever the caller does in between (the pass prologue stages the next query tile there).
+struct FlushTicket {
+    Cand e;
+    u32 pos;
+    bool live;
+};
 template <int NT>
-__device__ __forceinline__ void flush_stage(const ScanArgs& a, const TailLds& L, int n, int tid)
+__device__ __forceinline__ FlushTicket flush_begin(const ScanArgs& a, const TailLds& L, int half, int n, int tid)
 {
-    for (int i = tid; i < n; i += NT) {
-        const Cand e = L.stage[i];
+    FlushTicket f;
+    f.live = false;
+    f.pos = 0;
+    if (tid < n) {
+        f.e = L.stage[half * kStageHalf + tid];
+        f.live = (u32)(f.e.key >> 32) >= lds_get_bound(L, (int)(f.e.q >> 6), (int)(f.e.q & 63));
+        if (f.live) f.pos = atomicAdd(a.count + f.e.q, 1u);
+    }
+    return f;
+}
+template <int NT>
+__device__ __forceinline__ void flush_end(const ScanArgs& a, const TailLds& L, const FlushTicket& f, int half, int n, int tid)
+{
+    if (f.live && f.pos < (u32)kCandCap) a.list[(size_t)f.e.q * kCandCap + f.pos] = f.e;
+    for (int i = tid + NT; i < n; i += NT) {     // more entries than threads: the front runners of a launch
+        const Cand e = L.stage[half * kStageHalf + i];
         if ((u32)(e.key >> 32) >= lds_get_bound(L, (int)(e.q >> 6), (int)(e.q & 63))) append_direct(a, e.key, e.sec, e.q);
     }
 }
 
 // after the last block of the last pass: test what is still in the chains against the bound as it stands (no rendezvous: a
 // wave that ends early misses the last chunks of the late ones -- a slightly lower bound, a few per cent more entries)
-__device__ __forceinline__ void tail_drain(const ScanArgs& a, ScanTail& T, const TailLds& L, int lane, int64_t b0, int nbw)
+__device__ __forceinline__ void tail_drain(const ScanArgs& a, ScanTail& T, const TailLds& L, int half, int lane, int64_t b0, int nbw)
 {
     const int R = T.t < kAge ? T.t : kAge;   // values still untested: chain positions R - 1 .. 0
     if (a.filter && T.rc_due >= 0) { recompute_theta<true>(a, L, T.rc_pass, lane); T.rc_due = -1; }
@@ -490,7 +517,7 @@ __device__ __forceinline__ void tail_drain(const ScanArgs& a, ScanTail& T, const
                 pa_loaded = T.pa;
             }
             const u32 th0 = a.filter ? lds_get_bound(L, T.pa, b) : 0u, th1 = a.filter ? lds_get_bound(L, T.pa, 32 + b) : 0u;
-            test_aged(a, T, L, T.cf[0][pos], T.cs[0][pos], T.cf[1][pos], T.cs[1][pos], th0, th1, lane, b0, nbw);
+            test_aged(a, T, L, half, T.cf[0][pos], T.cs[0][pos], T.cf[1][pos], T.cs[1][pos], th0, th1, lane, b0, nbw);
         }
     }
 }
@@ -624,7 +651,7 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();                                                        \
     TailLds L;                                                                                                           \
     L.stage = reinterpret_cast<Cand*>(reinterpret_cast<char*>(qs) + (size_t)a.P * 1024);                                 \
-    L.ctl = reinterpret_cast<u32*>(L.stage + kStageCap);                                                                 \
+    L.ctl = reinterpret_cast<u32*>(L.stage + 2 * kStageHalf);                                                            \
     L.bound = L.ctl + 16;                                                                                                \
     if (tid < 16) L.ctl[tid] = 0;                                                                                        \
     const int cls = (int)((gw + blockIdx.x) % a.ncls); /* members of a class on every XCD and every wave slot */           \
@@ -632,29 +659,34 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     T.init()
 
 // pass prologue shared by both kernels: barriers, staged appends of the previous pass -> global lists, new query tile
-#define HIPRAG_PASS_PROLOGUE()                                                                                           \
+// pass prologue of both kernels: STAGE_TILE is the statement that writes the pass's query tile
+#define HIPRAG_PASS_PROLOGUE(STAGE_TILE)                                                                                 \
     const int qbase = pass * 64;                                                                                         \
     const bool wrap = pass + 1 < npass;                                                                                  \
-    int nstaged = 0;                                                                                                     \
+    int nprev = 0;                                                                                                       \
+    u32 total_prev = 0;                                                                                                  \
     if (pass) {                                                                                                          \
-        __syncthreads(); /* every wave is done with the previous tile and with its staged appends */                     \
-        nstaged = min((int)L.ctl[0], kStageCap);                                                                         \
-        refresh_bounds(a, L, pass - 1, wave, NWAVES, lane);                                                              \
+        refresh_bounds(a, L, pass - 1, wave, NWAVES, lane); /* its round trip overlaps the wait for the slower waves */  \
+        __syncthreads(); /* every wave is done with the previous tile and with the previous pass's staged appends */     \
+        total_prev = L.ctl[(pass - 1) & 1];                                                                              \
+        nprev = (int)min(total_prev - (((pass - 1) & 1) ? T.flushed1 : T.flushed0), (u32)kStageHalf);                    \
     }                                                                                                                    \
-    stage_query_tile<NT>(a, reinterpret_cast<bf16x8*>(qs), P2, qbase, tid);                                              \
-    if (pass) {                                                                                                          \
-        __syncthreads(); /* everybody has read the count; the bounds are in LDS */                                       \
-        if (tid == 0) L.ctl[0] = 0;                                                                                      \
-        flush_stage<NT>(a, L, nstaged, tid);                                                                             \
-    }                                                                                                                    \
+    const FlushTicket ft = flush_begin<NT>(a, L, (pass - 1) & 1, nprev, tid);                                            \
+    STAGE_TILE;                                                                                                          \
+    flush_end<NT>(a, L, ft, (pass - 1) & 1, nprev, tid);                                                                 \
+    if (pass) { if ((pass - 1) & 1) T.flushed1 = total_prev; else T.flushed0 = total_prev; }                             \
     __syncthreads()
 
 #define HIPRAG_SCAN_EPILOGUE()                                                                                           \
-    if (S > 0) tail_drain(a, T, L, lane, b0, nbw);                                                                       \
-    __syncthreads();                                                                                                     \
+    if (S > 0) tail_drain(a, T, L, (npass - 1) & 1, lane, b0, nbw);                                                      \
     refresh_bounds(a, L, npass - 1, wave, NWAVES, lane);                                                                 \
     __syncthreads();                                                                                                     \
-    flush_stage<NT>(a, L, min((int)L.ctl[0], kStageCap), tid);                                                           \
+    {                                                                                                                    \
+        const int hl = (npass - 1) & 1;                                                                                  \
+        const int nl = (int)min(L.ctl[hl] - (hl ? T.flushed1 : T.flushed0), (u32)kStageHalf);                            \
+        const FlushTicket fl = flush_begin<NT>(a, L, hl, nl, tid);                                                       \
+        flush_end<NT>(a, L, fl, hl, nl, tid);                                                                            \
+    }                                                                                                                    \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the tail's clamped re-arms are still in flight */                \
     if (a.stamps && lane == 0) a.stamps[2 * gw + 1] = wall_clock64()
 
@@ -676,7 +708,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
     const bf16x8* q0 = reinterpret_cast<const bf16x8*>(qs);
     const bf16x8* q1 = q0 + P2 * 64;
     for (int pass = 0; pass < npass; ++pass) {
-        HIPRAG_PASS_PROLOGUE();
+        HIPRAG_PASS_PROLOGUE(stage_query_tile<NT>(a, reinterpret_cast<bf16x8*>(qs), P2, qbase, tid));
         if (S <= 0) continue;
 
         int s = 0;
@@ -730,6 +762,44 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
     HIPRAG_SCAN_EPILOGUE();
 }
 
+// query tile of the q64 kernel: for piece pair pp and lane (h, b) the bf16 images of Q[b][16pp + 4h + 0..3] and
+// Q[b][16pp + 8 + 4h + 0..3] (the k order the A fragment gets from a PAIR of fp32 pieces), queries qbase + 0..31 then + 32..63;
+// hi parts only: |q - bf16(q)| is in the certificate's eps
+template <int NT>
+__device__ __forceinline__ void stage_query_tile_split(const ScanArgs& a, u32x4* qw, int npairs, int qbase, int tid)
+{
+    const bool vec_ok = (a.d & 3) == 0;
+    int tid_p = tid;
+    asm volatile("" : "+v"(tid_p));
+    for (int idx = tid_p; idx < 2 * npairs * 64; idx += NT) {
+        const int tile = idx >= npairs * 64;
+        const int u = idx - tile * npairs * 64;
+        const int pp = u >> 6, l = u & 63;
+        const int hh = l >> 5;
+        const int b = qbase + (l & 31) + 32 * tile;
+        float v[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int col = 8 * (2 * pp + half) + 4 * hh;
+            if (b < a.nq && vec_ok && col + 3 < a.d) {
+                const float4 t = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.d + col);
+                v[4 * half + 0] = t.x; v[4 * half + 1] = t.y; v[4 * half + 2] = t.z; v[4 * half + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    v[4 * half + jj] = (b < a.nq && col + jj < a.d) ? a.q[(int64_t)b * a.d + col + jj] : 0.f;
+            }
+        }
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        split_pair(v[0], v[1], h0, l0);
+        split_pair(v[2], v[3], h1, l1);
+        split_pair(v[4], v[5], h2, l2);
+        split_pair(v[6], v[7], h3, l3);
+        (void)l0; (void)l1; (void)l2; (void)l3;
+        qw[idx] = u32x4{h0, h1, h2, h3};
+    }
+}
+
 // q64: the fp32 rows, split on the fly.  Data layout: block of 32 rows = P pieces of 1 KiB, piece p, lane slot
 // piece_slot(h, r): X[32B + r][8p + 4h + 0..3]; a PAIR of pieces gives a lane the 8 k-values [16pp + 4h + 0..3] and
 // [16pp + 8 + 4h + 0..3] of its row -- so the query tile of this kernel holds, for piece pair pp and lane (h, b), the
@@ -754,53 +824,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_split_kernel(ScanArgs a)
     const bf16x8* q0 = reinterpret_cast<const bf16x8*>(qs);
     const bf16x8* q1 = q0 + npairs * 64;
     for (int pass = 0; pass < npass; ++pass) {
-        const int qbase = pass * 64;
-        const bool wrap = pass + 1 < npass;
-        int nstaged = 0;
-        if (pass) {
-            __syncthreads();
-            nstaged = min((int)L.ctl[0], kStageCap);
-            refresh_bounds(a, L, pass - 1, wave, NWAVES, lane);
-        }
-        {
-            u32x4* qw = reinterpret_cast<u32x4*>(qs);
-            const bool vec_ok = (a.d & 3) == 0;
-            int tid_p = tid;
-            asm volatile("" : "+v"(tid_p));
-            for (int idx = tid_p; idx < 2 * npairs * 64; idx += NT) {
-                const int tile = idx >= npairs * 64;
-                const int u = idx - tile * npairs * 64;
-                const int pp = u >> 6, l = u & 63;
-                const int hh = l >> 5;
-                const int b = qbase + (l & 31) + 32 * tile;
-                float v[8];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int col = 8 * (2 * pp + half) + 4 * hh;
-                    if (b < a.nq && vec_ok && col + 3 < a.d) {
-                        const float4 t = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.d + col);
-                        v[4 * half + 0] = t.x; v[4 * half + 1] = t.y; v[4 * half + 2] = t.z; v[4 * half + 3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            v[4 * half + jj] = (b < a.nq && col + jj < a.d) ? a.q[(int64_t)b * a.d + col + jj] : 0.f;
-                    }
-                }
-                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                split_pair(v[0], v[1], h0, l0);
-                split_pair(v[2], v[3], h1, l1);
-                split_pair(v[4], v[5], h2, l2);
-                split_pair(v[6], v[7], h3, l3);
-                (void)l0; (void)l1; (void)l2; (void)l3;
-                qw[idx] = u32x4{h0, h1, h2, h3};    // hi parts only: |q - bf16(q)| is in the certificate's eps
-            }
-        }
-        if (pass) {
-            __syncthreads();
-            if (tid == 0) L.ctl[0] = 0;
-            flush_stage<NT>(a, L, nstaged, tid);
-        }
-        __syncthreads();
+        HIPRAG_PASS_PROLOGUE(stage_query_tile_split<NT>(a, reinterpret_cast<u32x4*>(qs), npairs, qbase, tid));
         if (S <= 0) continue;
 
         int s = 0;
@@ -1556,7 +1580,7 @@ struct DenseIndex {
             sa.ncls = (int)std::max<int64_t>(1, std::min<int64_t>(kClasses, (nb + bpw - 1) / bpw));   // waves that own blocks
             if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2, 0, (size_t)scan_cus * kMaxScanWaves * 16, st));
             sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2 : nullptr;
-            const size_t scan_lds = (size_t)P * 1024 + (size_t)kStageCap * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
+            const size_t scan_lds = (size_t)P * 1024 + (size_t)2 * kStageHalf * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
             const bool one_pass = nq <= kPassQ;
             void (*scan)(ScanArgs);
             if (scan_mode == 3) {
