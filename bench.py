@@ -23,6 +23,8 @@ resident in HBM; `--legs none` skips them, N > 1 never runs them):
   legs.reference_shape  the call shape the reference itself uses: L2 metric (faiss.IndexFlatL2, rag/storage/faiss_index.py:123), k = 50
                     (page_retriever.py:81), ONE query per call (:81-83) -- p50 / p99 through hipidx_search with host arrays and through
                     the overlay's search_hip_by_vector (enrichment included) -- plus batched L2 / k = 50 throughput and its roofline
+  legs.ivf          IVF-Flat over the same rows (north_star's "flat-IP / IVF distance scan"): recall against the exact flat top-10, p50 of
+                    one query per call and the bytes a query reads, at nprobe 1 / 8 / 32 of 1024 lists
   legs.hybrid       BASELINE configs[2]: 1M chunks, dense top-50 + BM25 term-at-a-time top-50 + RRF -> top-10; the BM25
                     roofline is priced on the posting bytes the queries REQUEST (sum df * 8 B), not on SURVEY 8(d)'s
                     accumulator passes, which the tiled kernel does not make
@@ -237,6 +239,61 @@ def run_legs(torch, args, dev, index, queries, legs):
         del sh, ix
         torch.cuda.empty_cache()
 
+    def leg_ivf():
+        """BASELINE north_star's other scan: IVF-Flat over the same 1M rows (nlist = 1024) -- the approximate one-query mode.
+        Recall against the exact flat top-10 of the headline index, p50 of one query per call, and the bytes a query reads."""
+        from hiprag import HipIVFIndex
+        nlist = 1024
+        t1 = time.perf_counter()
+        x = torch.cat([gen_chunk(torch, c, min(chunk, n_rows - c * chunk), dev) for c in range((n_rows + chunk - 1) // chunk)])
+        iv = HipIVFIndex(DIM, nlist, "ip", device=dev.index)
+        iv.train_add(x, iters=6)
+        del x
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t1
+        nqr = 256
+        truth = index.search_device(queries[:nqr], TOPK)[2]
+        # SURVEY 8(d)'s "planted" queries: row i + 5 % noise, renormalised -- their nearest neighbour is known, and it lives in
+        # ONE list; the isotropic random queries above have no such structure (their neighbours are spread evenly over the
+        # lists, so recall on them is nprobe / nlist by construction: what IVF does on data without clusters)
+        gp = torch.Generator(device=dev)
+        gp.manual_seed(99)
+        prow = torch.arange(nqr, device=dev) * 3907 + 11
+        src = torch.cat([gen_chunk(torch, int(r) // chunk, min(chunk, n_rows - (int(r) // chunk) * chunk), dev)[int(r) % chunk][None] for r in prow.tolist()])
+        noise = torch.randn(src.shape, generator=gp, device=dev)
+        planted = src + 0.05 * noise / noise.norm(dim=1, keepdim=True)
+        planted = (planted / planted.norm(dim=1, keepdim=True)).contiguous()
+        torch.cuda.synchronize()
+        lens = np.sort(iv.list_lengths)[::-1]
+        res = {}
+        for nprobe in (1, 8, 32):
+            got = iv.search_device(queries[:nqr], TOPK, nprobe)[2]
+            top1 = iv.search_device(planted, 1, nprobe)[2][:, 0]
+            torch.cuda.synchronize()
+            planted_hit = float((top1 == prow).float().mean().item())
+            recall = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / TOPK for a, b in zip(got.cpu().numpy(), truth.cpu().numpy())]))
+            lat = []
+            for i in range(120):
+                qi = queries[i:i + 1]
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                iv.search_device(qi, TOPK, nprobe)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t2) * 1e3)
+            lat = np.sort(np.asarray(lat[20:]))
+            tb = _time_steps(torch, lambda: iv.search_device(queries[:nqr], TOPK, nprobe), 5, 2)
+            rows_q = nprobe * n_rows / nlist
+            res[f"nprobe_{nprobe}"] = {"planted_neighbour_found": round(planted_hit, 4), "recall_at_10_isotropic_queries": round(recall, 4), "p50_ms_single_query": round(float(lat[len(lat) // 2]), 4),
+                                       "batched_256_qps": round(nqr / tb, 1), "rows_scored_per_query_avg": int(rows_q),
+                                       "bytes_per_query_avg": int(rows_q * DIM * 4),
+                                       "batched_GBs": round(nqr * rows_q * DIM * 4 / tb / 1e9, 1)}
+        out["ivf"] = {"workload": f"IVF-Flat over the same {n_rows} x {DIM} rows, nlist {nlist}, inner product, top-{TOPK}; exact fp64 scores "
+                                  f"of the probed rows, approximate only in WHICH rows are probed (exact at nprobe = nlist)",
+                      "build_s": round(build_s, 1), "longest_list": int(lens[0]), "shortest_list": int(lens[-1]), **res,
+                      "flat_p50_ms_single_query_for_comparison": "see p50_ms_single_query_device_resident of the headline"}
+        iv.close()
+        torch.cuda.empty_cache()
+
     def leg_hybrid():
         N, V, depth, nq = n_rows, 262144, 50, 256
         t0 = time.time()
@@ -333,7 +390,7 @@ def run_legs(torch, args, dev, index, queries, legs):
         torch.cuda.empty_cache()
 
     # a leg that fails must not cost the headline line: its entry carries the error instead
-    for name, fn in (("fp32", leg_fp32), ("reference", leg_reference), ("hybrid", leg_hybrid), ("encoder", leg_encoder)):
+    for name, fn in (("fp32", leg_fp32), ("reference", leg_reference), ("ivf", leg_ivf), ("hybrid", leg_hybrid), ("encoder", leg_encoder)):
         if name not in legs:
             continue
         try:
@@ -546,7 +603,7 @@ def main():
                          "ShardedHybrid (one packed all-gather per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--legs", default="fp32,reference,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
+    ap.add_argument("--legs", default="fp32,reference,ivf,hybrid,encoder", help="extra single-GPU legs (N = 1 only): comma list or 'none'")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     ap.add_argument("--force-dist", action="store_true",

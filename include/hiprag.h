@@ -154,6 +154,23 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out);
  * 0 = off.  Two event records cost ~20 us of dispatch bubble between chained launches, hence the sampling.  get_stats syncs. */
 int32_t hipidx_enable_timing(uint64_t h, int32_t on);
 
+/* ---- IVF-Flat (BASELINE north_star: "the flat-IP / IVF distance scan"; the reference builds faiss.IndexFlatL2 only,
+ *      rag/storage/faiss_index.py:123 -- this is the approximate, low-latency one-query mode on top of the flat index) -------
+ * rows_h       a flat index whose rows are stored PERMUTED by inverted list: list l = stored rows
+ *              [list_offsets[l], list_offsets[l + 1]), every list starting on a 32-row block (pad with any rows);
+ *              orig_ids_host[stored row] = the id results carry, -1 for padding rows
+ * centroids_h  a flat index (same d, metric, device) over the nlist centroids, row l = centroid of list l
+ * A search scores, exactly (fp64 from the fp32 rows, the flat index's own re-score), every row of the nprobe lists whose
+ * centroids rank best for the query under the index's metric, and returns their top k in the canonical order.  It is
+ * approximate unless nprobe >= nlist, where the result equals the flat index's bit for bit.  k <= 256, nprobe <= 1000.
+ * The handle shares the two flat indexes (destroy it before them). */
+int32_t hipivf_create(uint64_t rows_h, uint64_t centroids_h, const int64_t* list_offsets_host, const int64_t* orig_ids_host,
+                      int32_t nlist, uint64_t* out_handle);
+int32_t hipivf_destroy(uint64_t h);
+int32_t hipivf_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t nprobe, double* out_scores64_dev,
+                          float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+int32_t hipivf_info(uint64_t h, int32_t* out_nlist, int64_t* out_stored_rows, int64_t* out_longest_list);
+
 /* ---- partial top-k merge (multi-GPU: after one all-gather of per-shard partial results) ---------------
  * in_scores64 / in_ids: n_parts blocks of [nq, k_in] (device), block p starting part_stride ELEMENTS after block
  * p-1 (0 = dense, nq*k_in) so both arrays can live interleaved in one all-gathered buffer.  Canonical comparator

@@ -1698,6 +1698,91 @@ Registry<DenseIndex>& reg()
     return r;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// IVF-Flat on top of the flat index (BASELINE north_star: "the flat-IP / IVF distance scan"; the reference itself builds
+// faiss.IndexFlatL2 only, rag/storage/faiss_index.py:123).  The rows are stored PERMUTED by inverted list in an ordinary
+// flat index (every list starts on a 32-row block; padding rows carry the original id -1), the nlist centroids in a second
+// one.  A search is: exact top-nprobe of the query among the centroids (the flat search above) -> every probed list is cut
+// into slices of kIvfRows rows, one workgroup per (query, list, slice) re-scores its rows in fp64 straight from the fp32
+// rows (the same rescore4 as the flat finish: a row's score is the same bits in both indexes) and keeps its best k ->
+// the canonical merge of the partial lists (hiprag_merge_topk_dev).  Approximate by construction unless nprobe = nlist,
+// where every row is scored and the result equals the flat index's bit for bit (tests/test_ivf_gpu.py).
+// Bound: HBM -- rows probed x d_pad x 4 bytes per query; there is nothing for 64 queries to share (each probes its own
+// lists), which is why the flat scan wins for batches and IVF for one query at a time.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kIvfRows = 256;   // rows per workgroup of the probe kernel
+struct IvfArgs {
+    const float4* xb;
+    const float* q;        // [nq, d]
+    const i64* probe;      // [nq, nprobe] list ids from the centroid search (-1 = no such list)
+    const i64* offs;       // [nlist + 1] first stored row of every list (multiples of 32)
+    const i64* orig;       // [stored rows] original id, -1 for padding
+    double* ps;            // [nprobe * smax][nq][k] partial scores
+    i64* pi;               //                         partial ids
+    int d, P, k, nq, nprobe, smax;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void ivf_probe_kernel(IvfArgs a)
+{
+    __shared__ u64 keys[kIvfRows];
+    __shared__ i64 ids[kIvfRows];
+    __shared__ KeyId red[2 * 4];
+    __shared__ float qv[kMaxDPad];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.y, part = blockIdx.x;
+    const int j = part / a.smax, sl = part - j * a.smax;
+    const int dpad = a.P * 8;
+    const i64 list = a.probe[(i64)q * a.nprobe + j];
+    i64 lo = 0, hi = 0;
+    if (list >= 0) {
+        lo = a.offs[list] + (i64)sl * kIvfRows;
+        hi = min(a.offs[list + 1], lo + kIvfRows);
+    }
+    const int n = hi > lo ? (int)(hi - lo) : 0;     // workgroup-uniform
+    double* ps = a.ps + ((i64)part * a.nq + q) * a.k;
+    i64* pi = a.pi + ((i64)part * a.nq + q) * a.k;
+    if (n == 0) {
+        for (int r = tid; r < a.k; r += 256) { ps[r] = METRIC == HIPRAG_METRIC_IP ? -DBL_MAX : DBL_MAX; pi[r] = -1; }
+        return;
+    }
+    for (int c = tid; c < dpad; c += 256) qv[c] = c < a.d ? a.q[(i64)q * a.d + c] : 0.f;
+    for (int c = tid; c < kIvfRows; c += 256) { keys[c] = 0; ids[c] = -1; }
+    __syncthreads();
+    for (int g = wave; g * 4 < n; g += 4) {
+        const i64 row0 = lo + (i64)g * 4;               // lists start on 32-row blocks and slices on 256 rows: quad-aligned
+        const double s = rescore4<METRIC>(a.xb, a.P, row0 / kRowsPerBlock, (int)(row0 % kRowsPerBlock), qv);
+        const i64 row = row0 + (lane & 3);
+        if (lane < 4) {
+            const i64 oid = row < hi ? a.orig[row] : -1;
+            keys[g * 4 + lane] = oid >= 0 ? ord64(METRIC == HIPRAG_METRIC_IP ? s : -s) : 0ull;
+            ids[g * 4 + lane] = oid;
+        }
+    }
+    __syncthreads();
+    wg_topk_rounds<256>(keys, ids, (n + 3) & ~3, a.k, red, [&](int r, u64 kk, i64 id) {
+        ps[r] = kk ? (METRIC == HIPRAG_METRIC_IP ? unord64(kk) : -unord64(kk)) : (METRIC == HIPRAG_METRIC_IP ? -DBL_MAX : DBL_MAX);
+        pi[r] = kk ? id : -1;
+    });
+}
+
+struct IvfIndex {
+    std::mutex mu;
+    std::shared_ptr<DenseIndex> rows, cents;
+    DevBuf offs, orig, probe64, probe_ids, ps, pi;
+    int nlist = 0;
+    i64 maxlen = 0;        // longest list, in stored rows
+    i64 probed_rows = 0, searches = 0;   // stats: stored rows of the probed lists, queries
+    std::vector<i64> offs_host;
+};
+
+Registry<IvfIndex>& ivf_reg()
+{
+    static Registry<IvfIndex> r;
+    return r;
+}
+
 #define GET_INDEX(h)                                                       \
     std::shared_ptr<DenseIndex> ix = reg().get(h);                         \
     if (!ix) { set_error("unknown dense index handle %llu", (unsigned long long)(h)); return HIPRAG_E_HANDLE; } \
@@ -1706,7 +1791,7 @@ Registry<DenseIndex>& reg()
 
 }  // namespace
 
-size_t clear_dense_registry() { return reg().clear(); }
+size_t clear_dense_registry() { ivf_reg().clear(); return reg().clear(); }
 }  // namespace hiprag
 
 using namespace hiprag;
@@ -2049,6 +2134,109 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             out->avg_scan_gap_ms = ordered && n > 1 ? (float)(gsum / (n - 1) / ix->wall_khz) : 0.f;
         }
     }
+    return HIPRAG_OK;
+}
+
+// ---- IVF-Flat ----------------------------------------------------------------------------------------------------------
+int32_t hipivf_create(uint64_t rows_h, uint64_t centroids_h, const int64_t* list_offsets_host, const int64_t* orig_ids_host,
+                      int32_t nlist, uint64_t* out_handle)
+{
+    HR_REQUIRE(out_handle && list_offsets_host && orig_ids_host && nlist > 0, "bad hipivf_create arguments");
+    std::shared_ptr<DenseIndex> rows = reg().get(rows_h), cents = reg().get(centroids_h);
+    if (!rows || !cents) { set_error("unknown dense index handle"); return HIPRAG_E_HANDLE; }
+    HR_REQUIRE(rows->d == cents->d && rows->metric == cents->metric && rows->device == cents->device,
+               "rows and centroids must agree in dimension, metric and device");
+    HR_REQUIRE(cents->ntotal == nlist, "the centroid index holds %lld rows, nlist is %d", (long long)cents->ntotal, nlist);
+    HR_REQUIRE(list_offsets_host[0] == 0 && list_offsets_host[nlist] == rows->ntotal, "list offsets must cover the stored rows [0, %lld)",
+               (long long)rows->ntotal);
+    auto iv = std::make_shared<IvfIndex>();
+    iv->rows = rows; iv->cents = cents; iv->nlist = nlist;
+    iv->offs_host.assign(list_offsets_host, list_offsets_host + nlist + 1);
+    for (int l = 0; l < nlist; ++l) {
+        const i64 len = list_offsets_host[l + 1] - list_offsets_host[l];
+        HR_REQUIRE(len >= 0 && list_offsets_host[l] % kRowsPerBlock == 0, "list %d must start on a 32-row block and not be negative", l);
+        iv->maxlen = std::max(iv->maxlen, len);
+    }
+    HR_CHECK_HIP(hipSetDevice(rows->device));
+    int32_t rc;
+    if ((rc = iv->offs.reserve((size_t)(nlist + 1) * 8))) return rc;
+    if ((rc = iv->orig.reserve((size_t)std::max<i64>(rows->ntotal, 1) * 8))) return rc;
+    HR_CHECK_HIP(hipMemcpy(iv->offs.p, list_offsets_host, (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice));
+    HR_CHECK_HIP(hipMemcpy(iv->orig.p, orig_ids_host, (size_t)rows->ntotal * 8, hipMemcpyHostToDevice));
+    *out_handle = ivf_reg().put(iv);
+    return HIPRAG_OK;
+}
+
+int32_t hipivf_destroy(uint64_t h)
+{
+    std::shared_ptr<IvfIndex> iv = ivf_reg().get(h);
+    if (!iv) { set_error("unknown IVF handle"); return HIPRAG_E_HANDLE; }
+    {
+        std::lock_guard<std::mutex> guard(iv->mu);
+        (void)hipSetDevice(iv->rows->device);
+        (void)hipDeviceSynchronize();
+    }
+    ivf_reg().erase(h);
+    return HIPRAG_OK;
+}
+
+int32_t hipivf_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t nprobe, double* out_scores64_dev,
+                          float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    std::shared_ptr<IvfIndex> iv = ivf_reg().get(h);
+    if (!iv) { set_error("unknown IVF handle"); return HIPRAG_E_HANDLE; }
+    std::lock_guard<std::mutex> guard(iv->mu);
+    HR_REQUIRE(nq >= 0 && k > 0 && k <= kIvfRows, "k must be in 1..%d (got %d)", kIvfRows, k);
+    HR_REQUIRE(nprobe > 0 && nprobe <= kMaxK, "nprobe must be in 1..%d (got %d)", kMaxK, nprobe);
+    if (nq == 0) return HIPRAG_OK;
+    HR_REQUIRE(q_dev && out_scores64_dev && out_ids_dev, "null device pointer");
+    DenseIndex& R = *iv->rows;
+    DenseIndex& C = *iv->cents;
+    HR_CHECK_HIP(hipSetDevice(R.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int np = std::min(nprobe, iv->nlist);
+    const int smax = (int)std::max<i64>(1, (iv->maxlen + kIvfRows - 1) / kIvfRows);
+    const int parts = np * smax;
+    const int qchunk = std::max(1, std::min(nq, 1024));
+    int32_t rc;
+    if ((rc = iv->probe64.reserve((size_t)qchunk * np * 8))) return rc;
+    if ((rc = iv->probe_ids.reserve((size_t)qchunk * np * 8))) return rc;
+    if ((rc = iv->ps.reserve((size_t)parts * qchunk * k * 8))) return rc;
+    if ((rc = iv->pi.reserve((size_t)parts * qchunk * k * 8))) return rc;
+    {
+        std::lock_guard<std::mutex> gr(R.mu);
+        if ((rc = R.wait_adds_stream(st))) return rc;
+    }
+    for (int o = 0; o < nq; o += qchunk) {
+        const int m = std::min(qchunk, nq - o);
+        const float* qo = q_dev + (i64)o * R.d;
+        {   // coarse quantiser: the exact flat search of the query among the centroids
+            std::lock_guard<std::mutex> gc(C.mu);
+            if ((rc = C.search_dev(qo, m, np, iv->probe64.as<double>(), nullptr, iv->probe_ids.as<int64_t>(), st))) return rc;
+        }
+        IvfArgs a;
+        a.xb = R.xb.as<float4>(); a.q = qo; a.probe = iv->probe_ids.as<i64>(); a.offs = iv->offs.as<i64>(); a.orig = iv->orig.as<i64>();
+        a.ps = iv->ps.as<double>(); a.pi = iv->pi.as<i64>(); a.d = R.d; a.P = R.P; a.k = k; a.nq = m; a.nprobe = np; a.smax = smax;
+        if (R.metric == HIPRAG_METRIC_IP) hipLaunchKernelGGL(ivf_probe_kernel<HIPRAG_METRIC_IP>, dim3(parts, m), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(ivf_probe_kernel<HIPRAG_METRIC_L2>, dim3(parts, m), dim3(256), 0, st, a);
+        HR_CHECK_HIP(hipGetLastError());
+        if ((rc = hiprag_merge_topk_dev(iv->ps.as<double>(), iv->pi.as<int64_t>(), parts, m, k, k, (int64_t)m * k, R.metric,
+                                        out_scores64_dev + (i64)o * k, out_scores_dev ? out_scores_dev + (i64)o * k : nullptr,
+                                        out_ids_dev + (i64)o * k, stream)))
+            return rc;
+    }
+    iv->searches += nq;
+    return HIPRAG_OK;
+}
+
+int32_t hipivf_info(uint64_t h, int32_t* out_nlist, int64_t* out_stored_rows, int64_t* out_longest_list)
+{
+    std::shared_ptr<IvfIndex> iv = ivf_reg().get(h);
+    if (!iv) { set_error("unknown IVF handle"); return HIPRAG_E_HANDLE; }
+    HR_REQUIRE(out_nlist && out_stored_rows && out_longest_list, "null out");
+    *out_nlist = iv->nlist;
+    *out_stored_rows = iv->rows->ntotal;
+    *out_longest_list = iv->maxlen;
     return HIPRAG_OK;
 }
 

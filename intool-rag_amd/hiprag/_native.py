@@ -76,6 +76,10 @@ SIGNATURES = {
     "hipidx_load": [c_char_p, c_int32, u64p],
     "hipidx_get_stats": [c_uint64, POINTER(HipIdxStats)],
     "hipidx_enable_timing": [c_uint64, c_int32],
+    "hipivf_create": [c_uint64, c_uint64, c_void_p, c_void_p, c_int32, u64p],
+    "hipivf_destroy": [c_uint64],
+    "hipivf_search_dev": [c_uint64, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    "hipivf_info": [c_uint64, i32p, i64p, i64p],
     "hiprag_merge_topk_dev": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p,
                               c_void_p, c_void_p, c_void_p],
     "hipbm25_create": [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, u64p],
