@@ -985,7 +985,7 @@ __device__ __forceinline__ void write_result(double* out64, float* out32, int64_
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K2: the finish -- ONE kernel, one 16-wave workgroup per query (rounds 1-2 took seven launches: select, re-score,
+// K2: the finish -- ONE kernel, one 8-wave workgroup per query (rounds 1-2 took seven launches: select, re-score,
 // final, three for "round B", exhaustive check):
 //   1. the query's candidate list -> LDS, dropping entries below the final thetac (they cannot matter: either the
 //      certificate holds with thetac as the bound of everything unseen, or the query goes to the exhaustive path);
@@ -1003,8 +1003,10 @@ __device__ __forceinline__ void write_result(double* out64, float* out32, int64_
 //   7. the workgroup leaves the query's scan state (count, thetac, class slots) zeroed for the next launch of the slot.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kListLds = kNoFilterGroups;   // groups of one query the finish ranks in LDS
-constexpr int kMaxRescore = 256;            // groups re-scored (tagged quads) per query
-constexpr int kMaxExpand = 40;              // groups whose other three quads are re-scored
+constexpr int kMaxRescore = 192;            // groups re-scored (tagged quads) per query
+constexpr int kMaxExpand = 24;              // groups whose other three quads are re-scored
+constexpr int kFinThreads = 512;            // 8 waves and <= 40 KiB of LDS: four workgroups per CU, so the 1024 queries of a small-shard
+                                            // launch are finished in ONE round of workgroups (16 waves / 55 KiB: two rounds, 0.14 ms)
 constexpr int kCandRows = 4 * kMaxRescore + 12 * kMaxExpand;
 constexpr int kMaxKFast = 128;              // deepest k of this path; beyond: exhaustive path for every query
 
@@ -1029,15 +1031,18 @@ struct FinArgs {
 };
 
 template <int METRIC>
-__global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
+__global__ __launch_bounds__(kFinThreads) void fin_kernel(FinArgs a)
 {
     __shared__ float qv[kMaxDPad];
-    __shared__ u64 lkey[kListLds];
-    __shared__ float lsec[kListLds];
+    // the unsorted list (lkey / lsec) is dead once it has been ranked into skey / ssec: the re-scored rows (ck / ci) overlay it
+    constexpr int kOverlay = kCandRows * 16 > kListLds * 12 ? kCandRows * 16 : kListLds * 12;
+    __shared__ __attribute__((aligned(16))) unsigned char overlay[kOverlay];
+    u64* lkey = reinterpret_cast<u64*>(overlay);
+    float* lsec = reinterpret_cast<float*>(overlay + kListLds * 8);
+    u64* ck = reinterpret_cast<u64*>(overlay);
+    i64* ci = reinterpret_cast<i64*>(overlay + kCandRows * 8);
     __shared__ u64 skey[kListLds];
     __shared__ float ssec[kListLds];
-    __shared__ u64 ck[kCandRows];
-    __shared__ i64 ci[kCandRows];
     __shared__ u64 tk[kMaxKFast];
     __shared__ i64 ti[kMaxKFast];
     __shared__ double dred[32];
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
 
     // query into LDS (zero padded), its exact |q|^2 and |q - bf16(q)|^2 (the scan's query tile holds bf16(q), RNE)
     double qpart = 0.0, dpart = 0.0;
-    for (int c = tid; c < dpad; c += 1024) {
+    for (int c = tid; c < dpad; c += kFinThreads) {
         const float vf = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
         qv[c] = vf;
         const double v = (double)vf, dv = v - (double)(float)(__bf16)vf;
@@ -1060,21 +1065,21 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
-    if (lane == 0) { dred[wave] = qpart; dred[16 + wave] = dpart; }
+    if (lane == 0) { dred[wave] = qpart; dred[16 + wave] = dpart; }   // kFinThreads / 64 <= 16 waves
     if (tid == 0) { s_n = 0; s_r1 = 0; s_expand = 0; }
     if (tid < k) { tk[tid] = 0; ti[tid] = -1; }
     const u32 cnt_raw = a.count[q];
     const u32 theta = a.filter ? a.thetac[q] : 0u;
     __syncthreads();
     double qn2 = 0.0, dq2 = 0.0;
-    for (int w = 0; w < 16; ++w) { qn2 += dred[w]; dq2 += dred[16 + w]; }
+    for (int w = 0; w < kFinThreads / 64; ++w) { qn2 += dred[w]; dq2 += dred[16 + w]; }
     const double eps = scan_eps<METRIC>(dpad, a.mode, qn2, (double)__uint_as_float(a.max_norm2_bits[0]), dq2,
                                         (double)__uint_as_float(a.max_norm2_bits[1]));
 
     // 1. list -> LDS
     const int n_in = (int)min(cnt_raw, (u32)kCandCap);
     const Cand* src = a.list + (size_t)q * kCandCap;
-    for (int i = tid; i < n_in; i += 1024) {
+    for (int i = tid; i < n_in; i += kFinThreads) {
         const Cand e = src[i];
         if ((u32)(e.key >> 32) >= theta) {
             const int p = atomicAdd(&s_n, 1);
@@ -1093,7 +1098,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
 
     // rows of groups [g0, g1) of the sorted list -> ck / ci[4j ..]
     auto rescore_groups = [&](int g0, int g1) {
-        for (int j = g0 + wave; j < g1; j += 16) {
+        for (int j = g0 + wave; j < g1; j += kFinThreads / 64) {
             const u64 e = skey[j];
             const u32 gid = packed_index(e);
             const int g = (int)(__float_as_uint(packed_value(e)) & 3u);
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
         __syncthreads();
         if (tid < k) { tk[tid] = 0; ti[tid] = -1; }
         __syncthreads();
-        for (int i = tid; i < nc; i += 1024) {
+        for (int i = tid; i < nc; i += kFinThreads) {
             const u64 mk = ck[i];
             if (mk == 0) continue;
             const i64 mi = ci[i];
@@ -1129,7 +1134,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
 
     if (!flag) {
         // 2. rank by counting
-        for (int i = tid; i < n; i += 1024) {
+        for (int i = tid; i < n; i += kFinThreads) {
             const u64 mine = lkey[i];
             int r = 0;
             for (int j = 0; j < n; ++j) r += lkey[j] > mine ? 1 : 0;
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
             const double t = kth_on_scan_scale<METRIC>(kth_key, qn2) - eps;
             float tf = t > -3.0e38 ? (float)t : -FLT_MAX;
             if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
-            for (int j = R0 + tid; j < n; j += 1024)
+            for (int j = R0 + tid; j < n; j += kFinThreads)
                 if (packed_value(skey[j]) >= tf) atomicMax(&s_r1, j + 1);
             __syncthreads();
             const int R1 = s_r1;
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
     if (!flag) {
         // 5. other quads of groups whose `second` could still reach the k-th score
         const double kth = kth_on_scan_scale<METRIC>(kth_key, qn2);
-        for (int j = tid; j < R; j += 1024) {
+        for (int j = tid; j < R; j += kFinThreads) {
             const float m2 = ssec[j];
             if (m2 > -1.0e38f && !(kth > (double)m2 + eps)) {
                 const int p = atomicAdd(&s_expand, 1);
@@ -1176,7 +1181,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(FinArgs a)
         const int ne = s_expand;
         if (ne > kMaxExpand) flag = true;
         else if (ne > 0) {
-            for (int x = wave; x < ne; x += 16) {
+            for (int x = wave; x < ne; x += kFinThreads / 64) {
                 const u64 e = skey[expand[x]];
                 const u32 gid = packed_index(e);
                 const int tagged = (int)(__float_as_uint(packed_value(e)) & 3u);
@@ -1623,7 +1628,7 @@ struct DenseIndex {
             fa.list = w.list.as<Cand>();
             fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.mode = scan_mode;
             fa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
-            hipLaunchKernelGGL(fin_kernel<METRIC>, dim3(nq), dim3(1024), 0, st, fa);
+            hipLaunchKernelGGL(fin_kernel<METRIC>, dim3(nq), dim3(kFinThreads), 0, st, fa);
             w.dirty = false;
         } else {
             hipLaunchKernelGGL(flag_all_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, flags, arrivals, fallback_counter(), nq);
