@@ -284,7 +284,7 @@ def test_deep_k_on_the_candidate_lists_and_beyond(gpu):
 
 def test_extension_of_the_rescored_prefix_ties_and_overflow(gpu):
     """Both scales: 120 exact copies of one row, each in a group of its own, tie for the top 50 of the query that equals
-    them -- more tied groups than the first batch re-scores (k + k/2 = 75), fewer than the finish may re-score (256) -- so
+    them -- more tied groups than the first batch re-scores (k + k/2 = 75), fewer than the finish may re-score (192) -- so
     that query is settled by the EXTENSION step of the finish, lowest ids first.  A zero query ties EVERY group: the list
     overflows and the exhaustive path answers.  Results exact throughout."""
     from hiprag import HipFlatIndex
