@@ -42,6 +42,12 @@ int32_t hiprag_version(void);
 const char* hiprag_last_error(void);
 int32_t hiprag_device_count(int32_t* out_count);
 int32_t hiprag_device_sync(int32_t device);
+/* The device's SCAN STREAM: one high-priority hipStream_t per device, owned by the library (valid until hiprag_shutdown).
+ * The hybrid calls run their dense leg on it; hosts that chain scans themselves (hipidx_search_begin_dev,
+ * hiphybrid_shard_begin_dev) pass it as scan_stream so that the kernels meant to run BESIDE a scan -- the finish of the
+ * previous launch, a BM25 leg, an all-gather -- do not take the scan's CUs first: a scan workgroup needs an empty CU, the
+ * others are many small workgroups, and the dispatcher serves the high-priority queue first (hipidx_set_spare_cus). */
+int32_t hiprag_scan_stream(int32_t device, void** out_stream);
 /* Optional process-level bracket: init checks that n_devices GPUs are visible (<= 0: at least one) and
  * creates their contexts up front; shutdown synchronises every device and drops every handle still registered (their
  * device memory goes with them) -- the reference has no counterpart, its indices live until the process exits
@@ -119,11 +125,14 @@ int32_t hipidx_launch_queries(uint64_t h, int32_t* out_n);
 int32_t hipidx_search_begin_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot, void* stream);
 int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, int32_t slot,
                                  double* out_scores64_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
-/* Leave n CUs out of the scan grid (default 0): the 64-query scan fills the register file of
- * every CU it runs on, so kernels of OTHER streams -- the tails of earlier launches, and at N > 1 the RCCL all-gather,
- * whose ranks spin until every peer has joined -- otherwise only run between scans.  Alone on a GPU that costs nothing
- * (0 spare CUs is 2-3 % faster than 8 at 1M rows); row-sharded serving sets 8.  Synchronises the device. */
+/* Leave n CUs out of the scan grid (default 0).  A scan workgroup takes a CU's whole LDS, so kernels of OTHER streams --
+ * the finish of the previous launch, the BM25 leg of a hybrid call, at N > 1 the RCCL all-gather, whose ranks spin until
+ * every peer has joined -- only run on CUs the scan leaves (or between scans).  The scan is HBM-bound and does not need
+ * every CU: at 1M x 1024 rows a launch takes the same time on 192 workgroups as on 256 and 5 % longer on 160.  Takes
+ * effect with the next launch, no synchronisation (the finish reads a launch's lists, never its partition).  The hybrid
+ * calls and the row-sharded hosts set it themselves (hiphybrid_search*: 80 for the dense leg of the call). */
 int32_t hipidx_set_spare_cus(uint64_t h, int32_t n);
+int32_t hipidx_get_spare_cus(uint64_t h, int32_t* out_n);
 /* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);
 /* Capacity for n_rows rows now (one allocation of each of the index's buffers; rows added later beyond it grow it by half
@@ -214,11 +223,21 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
  * What rag/query/retriever.py does per query batch with three calls, for hosts that bind the C-ABI directly: host
  * queries and term lists in, fused fp32 scores / ids out; the two result lists never leave the GPU.  Both handles must
  * live on the same device.  Row-sharded serving uses hiphybrid_shard_begin_dev / _end_dev below (the all-gather sits between
- * search and fusion -- ranks are global, so fusion has to follow the merge).  The BM25 leg runs on a library-owned helper stream beside the dense leg (they are independent; the
- * dense scan is HBM-bound, BM25 is not) and RRF behind both. */
+ * search and fusion -- ranks are global, so fusion has to follow the merge).
+ * The two legs are independent and bound by different things (the dense scan by HBM, BM25 by LDS round trips), so they run
+ * BESIDE each other: the dense leg on the device's scan stream (hiprag_scan_stream) with 80 CUs left out of its scan grid,
+ * the BM25 leg on the caller's stream, its workgroups filling those CUs, RRF behind both (1M chunks, 256 queries per call:
+ * 140-154 k hybrid queries/s against 123-137 k with the legs one after the other; identical results). */
 int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
                          const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
                          float w_sparse, float* out_scores, int64_t* out_ids);
+/* The same with the queries, the two intermediate lists and the results in device memory, ordered on `stream` (the legs
+ * start where `stream` is at the call; the fusion is enqueued on `stream` behind both legs; nothing synchronises).
+ * lists_dev: int64 [4][nq][depth] the caller provides = dense fp64 score bits | dense ids | BM25 fp64 score bits | BM25 ids
+ * (left there for callers that also want the per-leg lists, rag/query/retriever.py keeps both). */
+int32_t hiphybrid_search_dev(uint64_t dense_h, uint64_t bm25_h, const float* q_dev, const uint32_t* term_ids_host,
+                             const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
+                             float w_sparse, int64_t* lists_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
 /* ---- row-sharded hybrid step: the two halves around the caller's ONE all-gather (SURVEY 8b `hiphybrid_search(...)`, 8e) ----
  * One process per GPU holds the rows AND the postings of one contiguous document range (hipidx_set_id_base /
@@ -227,7 +246,9 @@ int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host,
  *                               (leg 0 dense, leg 1 BM25; [0] = fp64 score bits, [1] = ids).  The index scan is enqueued on
  *                               scan_stream (callers chain their scans there), everything after it on tail_stream, ordered
  *                               behind the scan by a library-owned event; `slot` (0..7) as in hipidx_search_begin_dev.
- *                               scratch_f32_dev: 2 * nq * depth floats.
+ *                               scratch_f32_dev: 2 * nq * depth floats.  For the tails to run BESIDE the next scan, pass
+ *                               the device's scan stream (hiprag_scan_stream) and leave the tails CUs
+ *                               (hipidx_set_spare_cus(dense_h, 80)): see hipidx_set_spare_cus and hiphybrid_search.
  *   (caller)                    all-gather of pack_dev over the ranks -> gathered_dev [n_parts][2][2][nq][depth]: RCCL, MPI,
  *                               whatever the host has; 4 * nq * depth * 8 bytes per rank
  *   hiphybrid_shard_end_dev     each leg merged over the parts with the canonical comparator (better score, then lower id),

@@ -1421,6 +1421,7 @@ struct DenseIndex {
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
+        HR_CHECK_HIP(hipStreamSynchronize(nullptr));   // hipMemset of device memory may return before the fill has run
         return HIPRAG_OK;
     }
 
@@ -1451,6 +1452,9 @@ struct DenseIndex {
         HR_CHECK_HIP(hipMemset(nx, 0, xbytes));
         HR_CHECK_HIP(hipMemset(nn, 0, nbytes));
         HR_CHECK_HIP(hipMemset(nh, 0, hbytes));
+        // hipMemset of device memory is ordered on the null stream but may return before the fill has run, and the kernels
+        // that write and read these buffers run on the callers' (non-blocking) streams
+        HR_CHECK_HIP(hipStreamSynchronize(nullptr));
         if (xb.p) {
             HR_CHECK_HIP(hipMemcpy(nx, xb.p, (size_t)cap_blocks * P * kPieceFloats * sizeof(float), hipMemcpyDeviceToDevice));
             HR_CHECK_HIP(hipMemcpy(nn, norms.p, (size_t)cap_blocks * kRowsPerBlock * sizeof(float), hipMemcpyDeviceToDevice));
@@ -1545,7 +1549,12 @@ struct DenseIndex {
         const size_t state_bytes = state_words(Q) * sizeof(u32);
         const bool fresh = w.state.bytes < state_bytes;
         if ((rc = w.state.reserve(state_bytes))) return rc;
-        if (fresh) HR_CHECK_HIP(hipMemset(w.state.p, 0, w.state.bytes));   // the finish keeps it clean from here on
+        if (fresh) {   // the finish keeps it clean from here on
+            // the fill is ordered on the null stream only and may still be pending when hipMemset returns; the scan that reads
+            // this state runs on a non-blocking stream (a garbage bound drops candidates: seen once as a two-rank mismatch)
+            HR_CHECK_HIP(hipMemset(w.state.p, 0, w.state.bytes));
+            HR_CHECK_HIP(hipStreamSynchronize(nullptr));
+        }
         if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
         if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
@@ -1583,8 +1592,8 @@ struct DenseIndex {
             sa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
             const int64_t bpw = scan_blocks_per_wave(nb, (int64_t)scan_cus * nw);
             sa.ncls = (int)std::max<int64_t>(1, std::min<int64_t>(kClasses, (nb + bpw - 1) / bpw));   // waves that own blocks
-            if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2, 0, (size_t)scan_cus * kMaxScanWaves * 16, st));
-            sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * scan_cus * kMaxScanWaves * 2 : nullptr;
+            if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2, 0, (size_t)n_cu * kMaxScanWaves * 16, st));
+            sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2 : nullptr;
             const size_t scan_lds = (size_t)P * 1024 + (size_t)2 * kStageHalf * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
             const bool one_pass = nq <= kPassQ;
             void (*scan)(ScanArgs);
@@ -1657,7 +1666,7 @@ struct DenseIndex {
             evs.resize(2 * kEvRing);
             ev_set.assign(kEvRing, 0);
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
-            int32_t src = stamps.reserve((size_t)kEvRing * scan_cus * kMaxScanWaves * 2 * sizeof(unsigned long long));
+            int32_t src = stamps.reserve((size_t)kEvRing * n_cu * kMaxScanWaves * 2 * sizeof(unsigned long long));
             if (src) return src;
             (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device);
             if (wall_khz <= 0) wall_khz = 100000;
@@ -1903,12 +1912,17 @@ int32_t hipidx_set_spare_cus(uint64_t h, int32_t n)
 {
     GET_INDEX(h);
     HR_REQUIRE(n >= 0 && n < ix->n_cu, "spare CUs must be in 0..%d", ix->n_cu - 1);
-    HR_CHECK_HIP(hipDeviceSynchronize());   // the finish kernels of launches in flight decode slots with the old partition
+    // takes effect with the next launch: the finish reads a launch's lists and bounds, never its partition, and the stamp
+    // buffer is sized for the whole chip
     ix->scan_cus = ix->n_cu - n;
-    ix->stamps.release();                   // sized by the scan grid
-    for (hipEvent_t e : ix->evs) (void)hipEventDestroy(e);
-    ix->evs.clear();                        // re-created (with the stamp buffer) by the next enable_timing + search
-    ix->timing = false;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_get_spare_cus(uint64_t h, int32_t* out_n)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(out_n, "null out");
+    *out_n = ix->n_cu - ix->scan_cus;
     return HIPRAG_OK;
 }
 
@@ -2118,7 +2132,7 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
         // the same launches on the GPU's own wall clock: first wave in -> last wave out, and the idle time between the
         // last wave of one scan and the first wave of the next (negative = the next scan started on CUs already free)
         if (ix->stamps.p && ix->nblocks() > 0) {
-            const size_t per = (size_t)ix->scan_cus * kMaxScanWaves * 2;
+            const size_t per = (size_t)ix->n_cu * kMaxScanWaves * 2;
             std::vector<unsigned long long> hst((size_t)n * per);
             HR_CHECK_HIP(hipMemcpy(hst.data(), ix->stamps.p, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             std::vector<std::pair<unsigned long long, unsigned long long>> se((size_t)n);

@@ -23,66 +23,126 @@ static Registry<hipEvent_t>& events()
     return r;
 }
 
-// Helper streams of hiphybrid_search (the BM25 leg runs beside the dense leg): owned by the library, not by the calling
-// thread -- a pool per process, entries tagged with their device, handed out under a mutex and destroyed by hiprag_shutdown.
-struct SideStream {
-    hipStream_t st = nullptr;
-    hipEvent_t done = nullptr;
+// The device's SCAN STREAM: one high-priority stream per device, owned by the library (hiprag_scan_stream hands it to
+// hosts that chain their own scans, hiprag/sharded.py).  A scan workgroup needs a whole CU (158 of 160 KiB of LDS) and a
+// scan is launched on fewer workgroups than the chip has CUs (hipidx_set_spare_cus); the kernels that are to run beside
+// it -- BM25 tiles, four to a CU, the finish of the previous launch -- are many small workgroups.  When a scan and such a
+// kernel become ready together the dispatcher serves the high-priority queue first: the scan gets its CUs and the small
+// workgroups fill the rest.  With equal priorities they take every CU first and the scan's workgroups start late, one by
+// one, as CUs drain (the hybrid legs' times then simply add up: 123-137 k hybrid queries/s at 1M chunks, against 140-154 k
+// beside each other on the same boxes).  Every dense leg of every hybrid call goes through this one stream, in the order
+// the index's mutex admitted the calls (they share the index's workspace).
+class ScanStreams {
+public:
+    int32_t get(int dev, hipStream_t& out)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = hp_.find(dev);
+        if (it == hp_.end()) {
+            int least = 0, greatest = 0, cur = 0;
+            hipStream_t hp = nullptr;
+            HR_CHECK_HIP(hipGetDevice(&cur));
+            HR_CHECK_HIP(hipSetDevice(dev));
+            hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&hp, hipStreamNonBlocking, greatest);
+            (void)hipSetDevice(cur);
+            HR_CHECK_HIP(e);
+            it = hp_.emplace(dev, hp).first;
+        }
+        out = it->second;
+        return HIPRAG_OK;
+    }
+    void clear()   // hiprag_shutdown, every device synchronised
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto& kv : hp_)
+            if (hipSetDevice(kv.first) == hipSuccess) (void)hipStreamDestroy(kv.second);
+        hp_.clear();
+    }
+
+private:
+    std::mutex mu_;
+    std::unordered_map<int, hipStream_t> hp_;
+};
+static ScanStreams& scan_streams()
+{
+    static ScanStreams s;
+    return s;
+}
+constexpr int kHybridSpareCus = 80;   // of 256: dense top-50 alone loses 0-2 % on 176 workgroups, BM25 keeps up on 80 CUs (config 2)
+
+// The two events of one hybrid call (legs start / dense leg done), pooled per device.
+struct LegEvents {
+    hipEvent_t in = nullptr, dense_done = nullptr;
     int dev = -1;
 };
-class SidePool {
+class LegEventPool {
 public:
-    int32_t acquire(int dev, SideStream& out)
+    int32_t acquire(int dev, LegEvents& out)
     {
         {
             std::lock_guard<std::mutex> g(mu_);
             for (size_t i = 0; i < free_.size(); ++i)
                 if (free_[i].dev == dev) { out = free_[i]; free_.erase(free_.begin() + (long)i); return HIPRAG_OK; }
         }
-        SideStream s;
-        s.dev = dev;
-        HR_CHECK_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-        hipError_t e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
-        if (e != hipSuccess) { (void)hipStreamDestroy(s.st); HR_CHECK_HIP(e); }
-        out = s;
+        LegEvents e;
+        e.dev = dev;
+        HR_CHECK_HIP(hipEventCreateWithFlags(&e.in, hipEventDisableTiming));
+        hipError_t rc = hipEventCreateWithFlags(&e.dense_done, hipEventDisableTiming);
+        if (rc != hipSuccess) { (void)hipEventDestroy(e.in); HR_CHECK_HIP(rc); }
+        out = e;
         return HIPRAG_OK;
     }
-    void release(const SideStream& s)
+    void release(const LegEvents& e)
     {
         std::lock_guard<std::mutex> g(mu_);
-        free_.push_back(s);
+        free_.push_back(e);
     }
-    void clear()   // hiprag_shutdown (every device has been synchronised): leases still out are destroyed by their holders' release -> here next time
+    void clear()
     {
         std::lock_guard<std::mutex> g(mu_);
-        for (const SideStream& s : free_) {
-            if (hipSetDevice(s.dev) != hipSuccess) continue;
-            (void)hipEventDestroy(s.done);
-            (void)hipStreamDestroy(s.st);
+        for (const LegEvents& e : free_) {
+            if (hipSetDevice(e.dev) != hipSuccess) continue;
+            (void)hipEventDestroy(e.in);
+            (void)hipEventDestroy(e.dense_done);
         }
         free_.clear();
     }
 
 private:
     std::mutex mu_;
-    std::vector<SideStream> free_;
+    std::vector<LegEvents> free_;
 };
-static SidePool& side_pool()
+static LegEventPool& leg_events()
 {
-    static SidePool p;
+    static LegEventPool p;
     return p;
 }
-// One lease per hiphybrid_search call.  While `busy` the helper stream may still write into buffers the call's frame owns:
-// every way out of the frame (error returns included) first waits for it, then hands the stream back.
-struct SideLease {
-    SideStream s;
+// One lease per hybrid call.  While `busy` the scan stream may still write into buffers the call's frame owns: every way out
+// of the frame (error returns included) first waits for it.
+struct LegLease {
+    LegEvents e;
+    hipStream_t hp = nullptr;
     bool held = false, busy = false;
-    ~SideLease()
+    ~LegLease()
     {
-        if (!held) return;
-        if (busy) (void)hipStreamSynchronize(s.st);
-        side_pool().release(s);
+        if (busy && hp) (void)hipStreamSynchronize(hp);
+        if (held) leg_events().release(e);
     }
+};
+
+// the dense leg of a hybrid call leaves CUs to the BM25 leg; the index's own setting comes back on every way out
+struct SpareCusScope {
+    uint64_t h = 0;
+    int32_t before = -1;
+    int32_t enter(uint64_t handle, int32_t spare)
+    {
+        int32_t rc = hipidx_get_spare_cus(handle, &before);
+        if (rc) { before = -1; return rc; }
+        h = handle;
+        return before >= spare ? HIPRAG_OK : hipidx_set_spare_cus(handle, spare);
+    }
+    ~SpareCusScope() { if (before >= 0) (void)hipidx_set_spare_cus(h, before); }
 };
 
 struct StepEvents {    // one event per (device, slot): orders a step's tail stream behind its scan
@@ -189,7 +249,8 @@ int32_t hiprag_shutdown(void)
     clear_bm25_registry();
     clear_dense_registry();
     events().clear();
-    side_pool().clear();
+    leg_events().clear();
+    scan_streams().clear();
     step_events().clear();
     return HIPRAG_OK;
 }
@@ -233,6 +294,43 @@ int32_t hiprag_probe_read_gbps(int32_t device, int64_t bytes, int32_t reps, doub
     return HIPRAG_OK;
 }
 
+int32_t hiphybrid_search_dev(uint64_t dense_h, uint64_t bm25_h, const float* q_dev, const uint32_t* term_ids_host,
+                             const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
+                             float w_sparse, int64_t* lists_dev, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    HR_REQUIRE(nq >= 0 && depth > 0 && k > 0, "bad hybrid shape");
+    if (nq == 0) return HIPRAG_OK;
+    HR_REQUIRE(q_dev && q_offsets_host && lists_dev && out_scores_dev && out_ids_dev, "null argument");
+    int32_t rc;
+    if ((rc = hipidx_reserve_search(dense_h, depth))) return rc;   // also makes the index's device current on this thread
+    int cur_dev = 0;
+    HR_CHECK_HIP(hipGetDevice(&cur_dev));
+    const size_t nd = (size_t)nq * depth;      // lists_dev: int64 [4][nq][depth] = dense score bits | dense ids | BM25 score bits | BM25 ids
+    hipStream_t main = (hipStream_t)stream;
+    LegLease lease;
+    if ((rc = scan_streams().get(cur_dev, lease.hp))) return rc;
+    if ((rc = leg_events().acquire(cur_dev, lease.e))) return rc;
+    lease.held = true;
+    // the dense leg starts where the caller's stream is now (whatever produced q_dev is ahead of it), on the scan stream ...
+    HR_CHECK_HIP(hipEventRecord(lease.e.in, main));
+    HR_CHECK_HIP(hipStreamWaitEvent(lease.hp, lease.e.in, 0));
+    lease.busy = true;
+    {
+        SpareCusScope spare;
+        if ((rc = spare.enter(dense_h, kHybridSpareCus))) return rc;
+        if ((rc = hipidx_search_dev(dense_h, q_dev, nq, depth, reinterpret_cast<double*>(lists_dev), nullptr, lists_dev + nd, lease.hp)))
+            return rc;
+    }
+    HR_CHECK_HIP(hipEventRecord(lease.e.dense_done, lease.hp));
+    // ... the BM25 leg beside it on the caller's stream, on the CUs the scan leaves (and on all of them once it is done) ...
+    if ((rc = hipbm25_search_dev(bm25_h, term_ids_host, q_offsets_host, nq, depth, reinterpret_cast<double*>(lists_dev + 2 * nd), nullptr,
+                                 lists_dev + 3 * nd, stream))) return rc;
+    // ... and the fusion behind both
+    HR_CHECK_HIP(hipStreamWaitEvent(main, lease.e.dense_done, 0));
+    lease.busy = false;   // from here the caller's stream orders everything that touches the caller's buffers
+    return hiprrf_fuse_dev(lists_dev + nd, lists_dev + 3 * nd, nq, depth, depth, k, c, w_dense, w_sparse, out_scores_dev, out_ids_dev, stream);
+}
+
 int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
                          const int32_t* q_offsets_host, int32_t nq, int32_t depth, int32_t k, float c, float w_dense,
                          float w_sparse, float* out_scores, int64_t* out_ids)
@@ -243,35 +341,19 @@ int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host,
     int32_t d = 0, rc;
     if ((rc = hipidx_dim(dense_h, &d))) return rc;
     if ((rc = hipidx_reserve_search(dense_h, depth))) return rc;   // also makes the index's device current on this thread
-    DevBuf q, s64a, ida, s64b, idb, os, oi;
-    const size_t nd = (size_t)nq * depth;
+    DevBuf q, lists, os, oi;
     if ((rc = q.reserve((size_t)nq * d * sizeof(float)))) return rc;
-    if ((rc = s64a.reserve(nd * 8))) return rc;
-    if ((rc = ida.reserve(nd * 8))) return rc;
-    if ((rc = s64b.reserve(nd * 8))) return rc;
-    if ((rc = idb.reserve(nd * 8))) return rc;
+    if ((rc = lists.reserve((size_t)4 * nq * depth * 8))) return rc;
     if ((rc = os.reserve((size_t)nq * k * sizeof(float)))) return rc;
     if ((rc = oi.reserve((size_t)nq * k * 8))) return rc;
     HR_CHECK_HIP(hipMemcpy(q.p, q_host, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice));
-    // The two legs are independent and use different parts of the chip -- the dense scan is HBM-bound, BM25 waits on LDS
-    // round trips and barriers -- so BM25 runs on a second stream beside the dense leg (its workgroups fill the gaps
-    // around the scan's tail kernels): 123-127 k -> 130-131 k hybrid queries/s at 1M chunks, same results.
-    int cur_dev = 0;
-    HR_CHECK_HIP(hipGetDevice(&cur_dev));
-    SideLease lease;   // declared AFTER the DevBufs: destroyed (= helper stream drained) before they are freed
-    if ((rc = side_pool().acquire(cur_dev, lease.s))) return rc;
-    lease.held = true;
-    lease.busy = true;   // from the first BM25 launch until the main stream has been made to wait for the leg and has drained
-    if ((rc = hipbm25_search_dev(bm25_h, term_ids_host, q_offsets_host, nq, depth, s64b.as<double>(), nullptr,
-                                 idb.as<int64_t>(), lease.s.st))) return rc;
-    HR_CHECK_HIP(hipEventRecord(lease.s.done, lease.s.st));
-    if ((rc = hipidx_search_dev(dense_h, q.as<float>(), nq, depth, s64a.as<double>(), nullptr, ida.as<int64_t>(), nullptr))) return rc;
-    HR_CHECK_HIP(hipStreamWaitEvent(nullptr, lease.s.done, 0));
-    if ((rc = hiprrf_fuse_dev(ida.as<int64_t>(), idb.as<int64_t>(), nq, depth, depth, k, c, w_dense, w_sparse,
-                              os.as<float>(), oi.as<int64_t>(), nullptr))) return rc;
+    rc = hiphybrid_search_dev(dense_h, bm25_h, q.as<float>(), term_ids_host, q_offsets_host, nq, depth, k, c, w_dense, w_sparse,
+                              lists.as<int64_t>(), os.as<float>(), oi.as<int64_t>(), nullptr);
+    // whatever the call enqueued (helper streams included: the null stream waits for them, or the call drained them on its
+    // error path) is done before the frame's buffers go
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
     HR_CHECK_HIP(hipMemcpy(out_scores, os.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     HR_CHECK_HIP(hipMemcpy(out_ids, oi.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
-    lease.busy = false;   // the blocking copies above ran behind the fusion, which waited for the BM25 leg
     return HIPRAG_OK;
 }
 
@@ -325,6 +407,16 @@ int32_t hiphybrid_shard_end_dev(const int64_t* gathered_dev, int32_t n_parts, in
                                     depth, (int64_t)part, HIPRAG_METRIC_IP, reinterpret_cast<double*>(sl_s), nullptr, sl_i, stream)))
         return rc;
     return hiprrf_fuse_dev(dl_i, sl_i, nq, depth, depth, k, c, w_dense, w_sparse, out_scores_dev, out_ids_dev, stream);
+}
+
+int32_t hiprag_scan_stream(int32_t device, void** out_stream)
+{
+    HR_REQUIRE(out_stream, "null out");
+    hipStream_t st = nullptr;
+    int32_t rc = scan_streams().get(device, st);
+    if (rc) return rc;
+    *out_stream = (void*)st;
+    return HIPRAG_OK;
 }
 
 int32_t hiprag_device_sync(int32_t device)

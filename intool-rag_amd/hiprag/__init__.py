@@ -17,3 +17,5 @@ def shutdown() -> None:
     """hiprag_shutdown: synchronise every device and drop every library handle still alive.  Python objects that wrap a
     handle must not be used afterwards (their close() then reports an unknown handle)."""
     _native.call("hiprag_shutdown")
+    from . import sharded
+    sharded._SCAN_STREAMS.clear()      # wrappers of the library's scan streams, destroyed with it

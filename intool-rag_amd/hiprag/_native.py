@@ -41,10 +41,13 @@ f32p, f64p, i64p, i32p, u32p, u64p = (POINTER(c_float), POINTER(c_double), POINT
 SIGNATURES = {
     "hiprag_device_count": [i32p],
     "hiprag_device_sync": [c_int32],
+    "hiprag_scan_stream": [c_int32, c_void_p],
     "hiprag_init": [c_int32],
     "hiprag_shutdown": [],
     "hiphybrid_search": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float,
                          c_float, c_void_p, c_void_p],
+    "hiphybrid_search_dev": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float,
+                             c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "hiphybrid_shard_begin_dev": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                   c_void_p, c_void_p],
     "hiphybrid_shard_end_dev": [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p,
@@ -69,6 +72,7 @@ SIGNATURES = {
     "hipidx_pass_queries": [c_uint64, i32p],
     "hipidx_launch_queries": [c_uint64, i32p],
     "hipidx_set_spare_cus": [c_uint64, c_int32],
+    "hipidx_get_spare_cus": [c_uint64, c_void_p],
     "hipidx_reserve_search": [c_uint64, c_int32],
     "hipidx_reserve_rows": [c_uint64, c_int64],
     "hipidx_reconstruct": [c_uint64, c_int64, c_void_p],

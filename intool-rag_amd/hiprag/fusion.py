@@ -58,28 +58,29 @@ def hybrid_search(index, bm25, queries, sparse_queries, depth: int = 50, k: int 
     return scores, ids
 
 
-_SIDE = {}
-
-
 def hybrid_search_device(index, bm25, q_dev, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0,
-                         w_dense: float = 1.0, w_sparse: float = 1.0):
-    """Device-resident form of hybrid_search: q_dev is a float32 CUDA tensor [nq, d]; returns (fused scores float32 [nq, k],
-    ids int64 [nq, k]) as CUDA tensors ordered on the current stream.  The BM25 leg runs on a helper stream beside the
-    dense leg (hiphybrid_search does the same: the legs are independent, the dense scan is HBM-bound and BM25 is not)."""
+                         w_dense: float = 1.0, w_sparse: float = 1.0, return_lists: bool = False):
+    """hiphybrid_search_dev, the device-resident form of hybrid_search: q_dev is a float32 CUDA tensor [nq, d]; returns
+    (fused scores float32 [nq, k], ids int64 [nq, k]) as CUDA tensors ordered on the current stream.  The library runs the
+    two legs beside each other (dense on its high-priority stream with CUs left out of the scan grid, BM25 on a helper
+    stream that fills them) and the fusion on the current stream behind both.  return_lists=True adds the two per-leg
+    lists: ((dense scores float64, dense ids), (BM25 scores float64, BM25 ids)), each [nq, depth]."""
     import torch
+    from .index import _stream_ptr
+    if not (q_dev.is_cuda and q_dev.dtype == torch.float32 and q_dev.dim() == 2 and q_dev.shape[1] == index.d
+            and q_dev.is_contiguous()):
+        raise ValueError("q_dev must be a contiguous float32 CUDA tensor [nq, d]")
+    nq = q_dev.shape[0]
+    if len(sparse_queries) != nq:
+        raise ValueError("one term list per query")
+    terms, qoff = bm25._flatten(sparse_queries)
     dev = q_dev.device
-    side = _SIDE.get(dev.index)
-    if side is None:
-        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream(dev)
-    ready = torch.cuda.Event()
-    ready.record(main)
-    side.wait_event(ready)            # whatever produced the caller's inputs is ahead of the BM25 leg too
-    with torch.cuda.stream(side):
-        sparse = bm25.search_device(sparse_queries, depth)
-        done = torch.cuda.Event()
-        done.record(side)
-    dense = index.search_device(q_dev, depth)
-    main.wait_event(done)
-    sparse[2].record_stream(main)
-    return rrf_fuse_device(dense[2], sparse[2], k, c=c, w_a=w_dense, w_b=w_sparse)
+    lists = torch.empty((4, nq, depth), dtype=torch.int64, device=dev)
+    out = (torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
+    if nq:
+        nat.call("hiphybrid_search_dev", index._h, bm25._h, q_dev.data_ptr(), terms.ctypes.data if terms.size else None,
+                 qoff.ctypes.data, nq, int(depth), int(k), float(c), float(w_dense), float(w_sparse), lists.data_ptr(),
+                 out[0].data_ptr(), out[1].data_ptr(), _stream_ptr())
+    if return_lists:
+        return out + (((lists[0].view(torch.float64), lists[1]), (lists[2].view(torch.float64), lists[3])),)
+    return out

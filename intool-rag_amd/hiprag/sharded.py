@@ -7,15 +7,20 @@ comparator is (score, id), the sharded result equals the unsharded one bit for b
 
 The reference is a single CPU process: this is new capability, not a port of anything.
 
-Pipelining.  The index scan is the only HBM-heavy stage; the finish, the exchange and the merge are latency-bound.
-With an exchange (N > 1) `search_begin` enqueues the scan (one launch of up to `launch_queries` queries = several passes over
-the local rows) on the caller's stream and everything after it on the stream of one of eight workspace slots, so that the
-exchange of earlier batches -- whose all-gather waits for the slowest rank -- runs beside later scans, on the CUs the scan
-grid leaves free; `search_end` enqueues the merge of the gathered partial lists and makes the caller's stream wait for it.
-WITHOUT an exchange (one GPU) the finish follows its scan on the caller's stream: a scan workgroup takes its CU's whole LDS,
-so a finish that is released together with the next scan either holds CUs that scan is statically partitioned over (its
-workgroups there start late and the launch ends late: measured 2.68-2.87 ms per launch against 2.49 alone) or waits for
-the scan after it; in stream order the finish costs its own 0.08 ms and nothing else (2.57 ms per 512-query step, 1M rows).
+Pipelining.  The index scan is the only HBM-heavy stage; the finish, the exchange and the merge are latency-bound, and a
+scan workgroup takes its CU's whole LDS, so nothing shares a CU with the scan.  But the scan does not need every CU: it is
+HBM-bound, and a launch over 1M x 1024 rows takes the same time on 208 workgroups as on 256.  So `search_begin` enqueues the
+scan (one launch of up to `launch_queries` queries = several passes over the local rows) on the index's own HIGH-PRIORITY
+stream with SPARE_CUS CUs left out of its grid, and everything after it -- the finish, at N > 1 the all-gather, whose
+ranks spin until every peer has joined, and the merge -- on the stream of one of eight workspace slots, where it runs
+BESIDE the next scan on the CUs that scan leaves; `search_end` makes the caller's stream wait for the result.  The
+priority is what makes the arrangement work: the next scan and the previous finish become ready at the same moment, and
+with equal priorities the finish's many small workgroups are placed first, on every CU, and the scan's workgroups (which
+need an EMPTY CU) start late and unevenly -- measured 2.68-2.87 ms per launch against 2.49 alone, which is why rounds 1-2
+ran the finish in stream order on one GPU.  With the scan served first: 1M rows 194.7 -> 199.5 k queries/s, 500 k rows
+374 -> 385 k, 125 k rows (the 8-GPU share) 1.09 -> 1.22 M, same box, A/B (`tools/scan_split_probe.py`); the idle time
+between two scans drops from 0.10-0.15 ms to 0.024.  `tails_aside=False` keeps the old arrangement (scan and finish in
+stream order on the caller's stream) for A/B runs.
 """
 from __future__ import annotations
 
@@ -25,6 +30,36 @@ from typing import List, Tuple
 from .index import HipFlatIndex, merge_topk_device
 
 N_SLOTS = 8     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
+SPARE_CUS = 48          # CUs a flat scan leaves to the tails of earlier launches (of 256; 32-64 measure the same)
+SPARE_CUS_HYBRID = 80   # ... when the tails include the BM25 leg (lib.cpp kHybridSpareCus)
+
+
+def _scan_stream(device):
+    """The device's scan stream (hiprag_scan_stream: the library's one high-priority stream per device, module docstring)
+    as a torch stream."""
+    import ctypes
+    import torch
+    from . import _native as nat
+    st = _SCAN_STREAMS.get(device)
+    if st is None:
+        ptr = ctypes.c_void_p()
+        nat.call("hiprag_scan_stream", int(device), ctypes.byref(ptr))
+        st = _SCAN_STREAMS[device] = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", int(device)))
+    return st
+
+
+def _order_behind(scan, main, ev) -> None:
+    """Whatever `main` (the caller's stream) holds now is ahead of what is enqueued on `scan` next.  An idle caller's stream
+    -- the steady state of a pipelined loop -- completes the marker within microseconds, and then the scan stream needs no
+    barrier packet in front of the scan at all (one is ~10 us between two scans); a busy one gets the barrier."""
+    ev.record(main)
+    for _ in range(8):
+        if ev.query():
+            return
+    scan.wait_event(ev)
+
+
+_SCAN_STREAMS = {}
 
 
 def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
@@ -87,8 +122,9 @@ def check_same_shape(shape: tuple, group=None) -> None:
 
 class ShardedFlatIndex:
     def __init__(self, local: HipFlatIndex, row_lo: int = 0, group=None, gather=None, tails_aside=None):
-        """tails_aside: None = the finish runs beside later scans (slot streams) exactly when there is an exchange to overlap
-        with, in stream order otherwise (module docstring); True / False force one arrangement (tests, A/B measurements)."""
+        """tails_aside: None / True = the finish (and the exchange) run beside later scans, the scans on the high-priority
+        stream (module docstring); False = scan and finish in stream order on the caller's stream (A/B measurements; not
+        with an exchange)."""
         import torch
         import torch.distributed as dist
         self.local = local
@@ -99,12 +135,13 @@ class ShardedFlatIndex:
         # the exchange (one all-gather per batch + merge) runs whenever there is more than one rank;
         # HIPRAG_FORCE_EXCHANGE=1 runs it on a one-rank group as well (a single-GPU box can then exercise the RCCL calls)
         self.exchange = _exchange_on(self.world)
-        self.tails_aside = self.exchange if tails_aside is None else bool(tails_aside) or self.exchange
+        self.tails_aside = True if tails_aside is None else bool(tails_aside) or self.exchange
         local.set_id_base(row_lo)
-        if self.exchange:
-            # the all-gather kernel of a step spins until every rank has launched it: give it (and the tails) CUs the scan
-            # never takes, or a rank that reaches its collective early holds CUs its own next scan is partitioned over
-            local.set_spare_cus(8)
+        # CUs the scan never takes: the tails of earlier launches run there beside it -- the finish, and with an exchange the
+        # all-gather kernel, which spins until every rank has launched it (a rank that reaches its collective early must not
+        # hold CUs its own next scan is partitioned over)
+        local.set_spare_cus(SPARE_CUS if self.tails_aside else 0)
+        self.scan = _scan_stream(local.device) if self.tails_aside else None
         # the tails (finish -> all-gather -> merge) run on two streams that the slots take turns on (_slot_streams): the
         # tail of batch i never queues behind that of batch i+1, which cannot start before scan i+1 ends; its merge,
         # enqueued at search_end, may sit behind the finish of batch i+2 -- a scan that is ahead of it on the caller's
@@ -148,6 +185,7 @@ class ShardedFlatIndex:
                                 torch.empty((nq, k), dtype=torch.float32, device=dev),
                                 torch.empty((nq, k), dtype=torch.int64, device=dev)) if self.exchange else None)
             cache["scanned"], cache["done"], cache["fin"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            cache["ready"] = torch.cuda.Event()
         return cache
 
     def search_begin(self, q, k: int):
@@ -162,24 +200,27 @@ class ShardedFlatIndex:
         slot, self._slot = self._slot, (self._slot + 1) % N_SLOTS
         main = torch.cuda.current_stream()
         c = self._buffers(slot, nq, k, q.device)
-        # Scans are chained on the caller's stream (one after the other, so a scan never shares the CUs with another
-        # scan and HIP events around a launch measure that launch); everything after the scan runs on the slot's own
-        # stream beside the next scans.
         side = self.side[slot]
         pack = c["pack"]
         if not self.tails_aside:
-            # one GPU, nothing to overlap with: scan and finish in stream order on the caller's stream (module docstring)
+            # A/B arrangement: scan and finish in stream order on the caller's stream (module docstring)
             self.local.search_begin(q, k, slot, stream=main.cuda_stream)
             self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=main.cuda_stream)
             self._slot_used[slot] = True
             self._slot_ended[slot] = True
             return (None, slot, k)
+        # Scans are chained on the index's high-priority stream (one after the other, so a scan never shares the CUs with
+        # another scan and HIP events around a launch measure that launch), behind whatever the caller's stream has
+        # enqueued so far (the queries; the caller's reads of the results this slot held eight batches ago); everything
+        # after the scan runs on the slot's own stream beside the next scans.
+        scan = self.scan
+        _order_behind(scan, main, c["ready"])
         if self._slot_used[slot] and not self._slot_ended[slot]:
-            # the pass that last used this slot must be complete; if its search_end already ran, the caller's stream
-            # waited there and stream order covers it (one barrier packet less per step)
-            main.wait_event(c["fin"] if self.exchange else c["done"])
-        self.local.search_begin(q, k, slot, stream=main.cuda_stream)
-        c["scanned"].record(main)
+            # the finish that last read this slot's workspace (its exchange and merge follow it on `side`); after a
+            # search_end(wait=True) the caller's stream has waited for it already
+            scan.wait_event(c["done"])
+        self.local.search_begin(q, k, slot, stream=scan.cuda_stream)
+        c["scanned"].record(scan)
         side.wait_event(c["scanned"])
         self._slot_used[slot] = True
         self._slot_ended[slot] = False
@@ -299,7 +340,7 @@ def _merge_and_fuse(gathered, depth: int, k: int, metric, c: float, w_dense: flo
 class ShardedHybrid:
     """Row-sharded hybrid search with the same pipeline as ShardedFlatIndex, as a client of the C-ABI's two halves
     (hiphybrid_shard_begin_dev / hiphybrid_shard_end_dev, include/hiprag.h): `search_begin` = one library call -- the dense
-    scan of the batch on the caller's stream; its finish and the BM25 leg on the stream of one of eight slots, filling the
+    scan of the batch on the high-priority scan stream; its finish and the BM25 leg on the stream of one of eight slots, filling the
     two halves of ONE packed buffer -- then the ONE all-gather (async) on that stream; `search_end` = one library call:
     the two global merges and the fusion.  Pre-allocated per-slot buffers; batches larger than the agreed launch size are
     cut into pipelined pieces."""
@@ -312,8 +353,10 @@ class ShardedHybrid:
         self.exchange = _exchange_on(self.world)     # see ShardedFlatIndex
         dense.set_id_base(row_lo)
         bm25.set_id_base(row_lo)
-        if self.exchange:
-            dense.set_spare_cus(8)          # room for the all-gather kernel beside the next scan (ShardedFlatIndex)
+        # the tails of a batch -- dense finish, BM25 leg, all-gather, merges, fusion -- run beside the next scans on the CUs
+        # the scan grid leaves, the scans on the high-priority stream (ShardedFlatIndex, module docstring)
+        dense.set_spare_cus(SPARE_CUS_HYBRID)
+        self.scan = _scan_stream(dense.device)
         self._max_pass = agree_min(dense.launch_queries, dense.device, group) if self.exchange else None
         self._check_shapes = self.exchange and os.environ.get("HIPRAG_CHECK_SHAPES") == "1"
         self.side = _slot_streams(dense.device)
@@ -343,7 +386,7 @@ class ShardedHybrid:
             c["merged"] = torch.empty((4, nq, depth), dtype=torch.int64, device=dev)       # scratch of hiphybrid_shard_end_dev
             c["fused"] = (torch.empty((nq, k), dtype=torch.float32, device=dev),
                           torch.empty((nq, k), dtype=torch.int64, device=dev))
-            c["fin"] = torch.cuda.Event()
+            c["fin"], c["ready"] = torch.cuda.Event(), torch.cuda.Event()
         return c
 
     def search_begin(self, q, sparse_queries, depth: int = 50, k: int = 10, c: float = 60.0, w_dense: float = 1.0,
@@ -362,11 +405,13 @@ class ShardedHybrid:
         main = torch.cuda.current_stream()
         b = self._buffers(slot, nq, depth, k, q.device)
         side, pack = self.side[slot], b["pack"]
+        scan = self.scan
+        _order_behind(scan, main, b["ready"])    # the queries; the caller's reads of the results this slot held eight batches ago
         if self._used[slot] and not self._ended[slot]:
-            main.wait_event(b["fin"])
+            scan.wait_event(b["fin"])            # the batch that last used the slot's workspace and buffers
         terms, qoff = self.bm25._flatten(sparse_queries)
         nat.call("hiphybrid_shard_begin_dev", self.dense._h, self.bm25._h, q.data_ptr(), terms.ctypes.data if terms.size else None,
-                 qoff.ctypes.data, nq, int(depth), slot, pack.data_ptr(), b["s32"].data_ptr(), ctypes.c_void_p(main.cuda_stream),
+                 qoff.ctypes.data, nq, int(depth), slot, pack.data_ptr(), b["s32"].data_ptr(), ctypes.c_void_p(scan.cuda_stream),
                  ctypes.c_void_p(self._side_ptr[slot]))
         self._used[slot], self._ended[slot] = True, False
         work = None

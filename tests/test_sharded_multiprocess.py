@@ -190,7 +190,7 @@ def _gpu_hybrid_worker(rank, world, port, q_out):
         local.add(x[lo:hi])
         full = PostingsCSR(p.n_docs, p.n_terms, p.offsets, p.doc_ids, p.impacts)
         sh = ShardedHybrid(local, HipBM25(full.shard(lo, hi)), lo, gather=list_gather)
-        assert sh.world == world and sh.max_pass == 64
+        assert sh.world == world and sh.max_pass == 64, (sh.world, sh.max_pass)
         qd = torch.from_numpy(q).cuda()
         _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
         _, bi = ho.bm25_search(p, sq, depth)
@@ -198,7 +198,14 @@ def _gpu_hybrid_worker(rank, world, port, q_out):
             fs, fi = sh.search_device(qd, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
             torch.cuda.synchronize()
             es, ei = ho.rrf_fuse(di, bi, k, c=c, w_a=wd, w_b=ws)
-            assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es)
+            gi, gs = fi.cpu().numpy(), fs.cpu().numpy()
+            bad = np.flatnonzero((gi != ei).any(axis=1) | (gs != es).any(axis=1))
+            if bad.size:    # say whether a repeat of the same call agrees (a race) or not (a wrong result)
+                fs2, fi2 = sh.search_device(qd, sq, depth=depth, k=k, c=c, w_dense=wd, w_sparse=ws)
+                torch.cuda.synchronize()
+                again = bool(np.array_equal(fi2.cpu().numpy(), ei) and np.array_equal(fs2.cpu().numpy(), es))
+                raise AssertionError(f"fused lists differ from the oracle's for queries {bad.tolist()[:24]} ({bad.size} of {nq}; "
+                                     f"weights {wd}, {ws}); the same call repeated {'agrees' if again else 'differs again'}")
         q_out.put((rank, "ok"))
     except Exception as e:
         q_out.put((rank, repr(e)))
