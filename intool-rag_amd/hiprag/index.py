@@ -133,8 +133,15 @@ class HipFlatIndex:
         return n.value
 
     def set_spare_cus(self, n: int) -> None:
-        """Leave n CUs out of the scan grid for kernels of other streams (tails, the RCCL all-gather); see hiprag.h."""
+        """Leave n CUs out of the scan grid for kernels of other streams (the finish of the previous launch, a BM25 leg, the
+        RCCL all-gather); takes effect with the next launch.  See hipidx_set_spare_cus in hiprag.h."""
         nat.call("hipidx_set_spare_cus", self._h, int(n))
+
+    @property
+    def spare_cus(self) -> int:
+        n = ctypes.c_int32()
+        nat.call("hipidx_get_spare_cus", self._h, ctypes.byref(n))
+        return n.value
 
     def reserve_search(self, k: int) -> None:
         nat.call("hipidx_reserve_search", self._h, int(k))

@@ -429,8 +429,10 @@ def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
 @pytest.mark.parametrize("tails", ["in_stream_order", "aside"])
 def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
     """Six launches in flight over the eight workspace slots, batch size and k changing from launch to launch (every slot's
-    buffers are re-shaped while older launches are still running), in both arrangements of the finish: behind its scan on the
-    caller's stream (one GPU) and on the slot streams beside later scans (what row-sharded serving does around its exchange)."""
+    buffers are re-shaped while older launches are still running), in both arrangements of the finish: on the slot streams
+    beside later scans, which run on the library's high-priority scan stream (the default), and behind its scan on the
+    caller's stream (the A/B arrangement).  The number of CUs the scan leaves free changes between launches in flight too
+    (hipidx_set_spare_cus takes effect per launch, no synchronisation)."""
     import torch
     from collections import deque
     from hiprag import HipFlatIndex
@@ -445,7 +447,9 @@ def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
     rng = np.random.default_rng(5)
     plan = [(int(rng.choice([1, 17, 64, 65, 200, 256])), int(rng.choice([1, 10, 50]))) for _ in range(40)]
     pending, got = deque(), []
-    for nq, k in plan:
+    for i, (nq, k) in enumerate(plan):
+        ix.set_spare_cus([48, 0, 200, 17][i % 4])
+        assert ix.spare_cus == [48, 0, 200, 17][i % 4]
         pending.append((nq, k, sh.search_begin(qd[:nq], k)))
         if len(pending) >= 6:
             a, b, t = pending.popleft()

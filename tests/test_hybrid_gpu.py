@@ -535,8 +535,11 @@ def test_bm25_tiled_and_global_accumulator_forms_agree_with_the_oracle(gpu, monk
 
 
 def test_hybrid_search_device_overlaps_the_legs_and_equals_the_oracle(gpu):
-    """hiprag.hybrid_search_device (BM25 on a helper stream beside the dense leg) and the one-call C path
-    hiphybrid_search (same overlap inside the library): fused lists bit-exact vs the oracle, call after call."""
+    """hiphybrid_search_dev (hiprag.hybrid_search_device: the dense leg on the library's high-priority scan stream with
+    CUs left out of its grid, BM25 beside it on the caller's stream, the fusion behind both) and the host-array call
+    hiphybrid_search around it: fused lists bit-exact vs the oracle call after call, from the default stream and from a
+    stream of the caller's; the per-leg lists the call leaves behind equal the oracle's; the index's own spare-CU
+    setting survives the call."""
     import torch
     from hiprag import HipBM25, HipFlatIndex, hybrid_search, hybrid_search_device
     n, d, depth, k, nq = 30000, 128, 50, 10, 70
@@ -548,12 +551,24 @@ def test_hybrid_search_device_overlaps_the_legs_and_equals_the_oracle(gpu):
     ix.add(x)
     bm = HipBM25(_gpu_postings(p))
     _, di = ho.flat_search(x, q, depth, ho.METRIC_IP)
-    _, bi = ho.bm25_search(p, sq, depth)
+    bs, bi = ho.bm25_search(p, sq, depth)
     es, ei = ho.rrf_fuse(di, bi, k)
     qd = torch.from_numpy(q).cuda()
+    ix.set_spare_cus(3)
     for _ in range(4):
         fs, fi = hybrid_search_device(ix, bm, qd, sq, depth=depth, k=k)
         torch.cuda.synchronize()
         assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es)
         hs, hi = hybrid_search(ix, bm, q, sq, depth=depth, k=k)
         assert np.array_equal(hi, ei) and np.array_equal(hs, es)
+    assert ix.spare_cus == 3
+    mine = torch.cuda.Stream()
+    with torch.cuda.stream(mine):
+        q2 = qd * 1.0                                  # produced on the caller's stream right before the call
+        fs, fi, ((d64, dids), (b64, bids)) = hybrid_search_device(ix, bm, q2, sq, depth=depth, k=k, return_lists=True)
+        total = fs.sum()                               # consumed on it right after
+    mine.synchronize()
+    assert np.array_equal(fi.cpu().numpy(), ei) and np.array_equal(fs.cpu().numpy(), es) and np.isfinite(float(total))
+    assert np.array_equal(dids.cpu().numpy(), di) and np.array_equal(bids.cpu().numpy(), bi)
+    assert np.array_equal(b64.cpu().numpy().astype(np.float32), bs) and d64.shape == (nq, depth)
+    assert hybrid_search_device(ix, bm, qd[:0], [], depth=depth, k=k)[1].shape == (0, k)
