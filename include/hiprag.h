@@ -130,7 +130,7 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
  * every peer has joined -- only run on CUs the scan leaves (or between scans).  The scan is HBM-bound and does not need
  * every CU: at 1M x 1024 rows a launch takes the same time on 192 workgroups as on 256 and 5 % longer on 160.  Takes
  * effect with the next launch, no synchronisation (the finish reads a launch's lists, never its partition).  The hybrid
- * calls and the row-sharded hosts set it themselves (hiphybrid_search*: 80 for the dense leg of the call). */
+ * calls and the row-sharded hosts set it themselves (hiphybrid_search*: 96 for the dense leg of the call). */
 int32_t hipidx_set_spare_cus(uint64_t h, int32_t n);
 int32_t hipidx_get_spare_cus(uint64_t h, int32_t* out_n);
 /* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
@@ -225,7 +225,7 @@ int32_t hiprrf_fuse_dev(const int64_t* ids_a_dev, const int64_t* ids_b_dev, int3
  * live on the same device.  Row-sharded serving uses hiphybrid_shard_begin_dev / _end_dev below (the all-gather sits between
  * search and fusion -- ranks are global, so fusion has to follow the merge).
  * The two legs are independent and bound by different things (the dense scan by HBM, BM25 by LDS round trips), so they run
- * BESIDE each other: the dense leg on the device's scan stream (hiprag_scan_stream) with 80 CUs left out of its scan grid,
+ * BESIDE each other: the dense leg on the device's scan stream (hiprag_scan_stream) with 96 CUs left out of its scan grid,
  * the BM25 leg on the caller's stream, its workgroups filling those CUs, RRF behind both (1M chunks, 256 queries per call:
  * 140-154 k hybrid queries/s against 123-137 k with the legs one after the other; identical results). */
 int32_t hiphybrid_search(uint64_t dense_h, uint64_t bm25_h, const float* q_host, const uint32_t* term_ids_host,
@@ -248,7 +248,7 @@ int32_t hiphybrid_search_dev(uint64_t dense_h, uint64_t bm25_h, const float* q_d
  *                               behind the scan by a library-owned event; `slot` (0..7) as in hipidx_search_begin_dev.
  *                               scratch_f32_dev: 2 * nq * depth floats.  For the tails to run BESIDE the next scan, pass
  *                               the device's scan stream (hiprag_scan_stream) and leave the tails CUs
- *                               (hipidx_set_spare_cus(dense_h, 80)): see hipidx_set_spare_cus and hiphybrid_search.
+ *                               (hipidx_set_spare_cus(dense_h, 96)): see hipidx_set_spare_cus and hiphybrid_search.
  *   (caller)                    all-gather of pack_dev over the ranks -> gathered_dev [n_parts][2][2][nq][depth]: RCCL, MPI,
  *                               whatever the host has; 4 * nq * depth * 8 bytes per rank
  *   hiphybrid_shard_end_dev     each leg merged over the parts with the canonical comparator (better score, then lower id),

@@ -412,8 +412,18 @@ struct Bm25Index {
     std::vector<uint64_t> offsets;  // host copy: planning happens on the host
     DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg, theta_dev, hist_dev;
     std::vector<i64> skip_index;         // per term: first entry of its skip table, or -1 (short lists)
-    std::vector<TileSlot> plan_slots;    // host staging of the last query plan (kept alive for the async copy)
-    std::vector<int> plan_nslots;
+    // Host staging of the query plans: a ring of pinned buffers, each with the event of its last copy.  A call fills the next
+    // buffer and enqueues its copies without waiting for anything but THAT buffer's previous copy (kStages calls ago), so a
+    // host that pipelines batches (ShardedHybrid: the BM25 leg of step i beside the scan of step i + 1) is not held until
+    // the previous call's kernels have run -- with one pageable staging vector every call blocked on its predecessor.
+    static constexpr int kStages = 4;
+    struct Stage {
+        PinBuf slots, nslots;
+        hipEvent_t ev = nullptr;
+        bool used = false;
+    };
+    Stage stages[kStages];
+    unsigned stage_next = 0;
     bool force_global = false;           // HIPBM25_GLOBAL_ACC=1: the global-accumulator form for every k (A/B runs)
     int ws_k = 0;
     i64 queries = 0, postings_touched = 0, bytes_alg = 0;
@@ -443,11 +453,14 @@ struct Bm25Index {
         int32_t rc;
         int max_slots = 1;
         for (int b = 0; b < nq; ++b) max_slots = std::max(max_slots, qoff[b + 1] - qoff[b]);
-        // the previous call's plan copy must have left the host staging vectors (whatever stream it ran on)
-        if (prev_ev_set) HR_CHECK_HIP(hipEventSynchronize(prev_ev));
-        else HR_CHECK_HIP(hipStreamSynchronize(st));
-        plan_slots.assign((size_t)nq * max_slots, TileSlot{0, 0, -1});
-        plan_nslots.assign((size_t)nq, 0);
+        Stage& sg = stages[stage_next++ % kStages];
+        if (sg.used) HR_CHECK_HIP(hipEventSynchronize(sg.ev));   // this buffer's previous copy (kStages calls ago) has left it
+        const size_t n_slots = (size_t)nq * max_slots;
+        if ((rc = sg.slots.reserve(n_slots * sizeof(TileSlot)))) return rc;
+        if ((rc = sg.nslots.reserve((size_t)nq * sizeof(int)))) return rc;
+        TileSlot* plan_slots = sg.slots.as<TileSlot>();
+        int* plan_nslots = sg.nslots.as<int>();
+        for (size_t i = 0; i < n_slots; ++i) plan_slots[i] = TileSlot{0, 0, -1};
         for (int b = 0; b < nq; ++b) {
             const int nt = qoff[b + 1] - qoff[b];
             plan_nslots[b] = nt;
@@ -465,12 +478,15 @@ struct Bm25Index {
             if ((rc = dbg.reserve((size_t)nq * ntiles() * 64))) return rc;
             dbg_p = dbg.as<unsigned long long>();
         }
-        if ((rc = slots_dev.reserve(plan_slots.size() * sizeof(TileSlot)))) return rc;
-        if ((rc = nslots_dev.reserve(plan_nslots.size() * sizeof(int)))) return rc;
+        if ((rc = slots_dev.reserve(n_slots * sizeof(TileSlot)))) return rc;
+        if ((rc = nslots_dev.reserve((size_t)nq * sizeof(int)))) return rc;
         if ((rc = ck.reserve((size_t)nq * lists * k * sizeof(u64)))) return rc;
         if ((rc = ci.reserve((size_t)nq * lists * k * sizeof(i64)))) return rc;
-        HR_CHECK_HIP(hipMemcpyAsync(slots_dev.p, plan_slots.data(), plan_slots.size() * sizeof(TileSlot), hipMemcpyHostToDevice, st));
-        HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots.data(), plan_nslots.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HR_CHECK_HIP(hipMemcpyAsync(slots_dev.p, plan_slots, n_slots * sizeof(TileSlot), hipMemcpyHostToDevice, st));
+        HR_CHECK_HIP(hipMemcpyAsync(nslots_dev.p, plan_nslots, (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
+        if (!sg.ev) HR_CHECK_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+        HR_CHECK_HIP(hipEventRecord(sg.ev, st));
+        sg.used = true;
         if ((rc = theta_dev.reserve((size_t)nq * sizeof(u32)))) return rc;
         HR_CHECK_HIP(hipMemsetAsync(theta_dev.p, 0, (size_t)nq * sizeof(u32), st));
         u32* hist_p = nullptr;
@@ -541,7 +557,12 @@ struct Bm25Index {
         return HIPRAG_OK;
     }
 
-    ~Bm25Index() { if (prev_ev) (void)hipEventDestroy(prev_ev); }
+    ~Bm25Index()
+    {
+        if (prev_ev) (void)hipEventDestroy(prev_ev);
+        for (Stage& sg : stages)
+            if (sg.ev) (void)hipEventDestroy(sg.ev);
+    }
 
     int32_t search_dev_impl(const uint32_t* terms, const int32_t* qoff, int nq, int k, double* o64p, float* o32p, i64* oidp,
                             hipStream_t st)

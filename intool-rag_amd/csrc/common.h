@@ -96,6 +96,28 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Pinned host buffer (device-visible under the same address): staging for asynchronous copies that must not block the host,
+// and a place kernels can write small results to directly.
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int32_t reserve(size_t want)
+    {
+        if (want <= bytes) return HIPRAG_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        if (want < 4096) want = 4096;
+        HR_CHECK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        bytes = want;
+        return HIPRAG_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // hiprag_shutdown: every translation unit owns the registry of its handle type
 size_t clear_dense_registry();
 size_t clear_bm25_registry();

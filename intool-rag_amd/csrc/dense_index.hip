@@ -1018,6 +1018,7 @@ struct FinArgs {
     float* out32;              // [nq, k] or null
     int64_t* out_ids;          // [nq, k]
     int* flags;                // [nq]
+    int* host_flags;           // [nq] a copy of the flags in pinned host memory, or null (hipidx_search's one-query path)
     int* arrivals;             // [nq] exhaustive-path arrival counters, zeroed here
     unsigned long long* fallback_counter;   // queries sent to the exhaustive path
     unsigned long long* extend_counter;     // queries whose re-scored prefix had to be extended (step 4)
@@ -1211,6 +1212,7 @@ __global__ __launch_bounds__(kFinThreads) void fin_kernel(FinArgs a)
     if (tid < k) write_result<METRIC>(a.out64, a.out32, a.out_ids, (int64_t)q * k + tid, tk[tid], ti[tid], a.id_base);
     if (tid == 0) {
         a.flags[q] = flag ? 1 : 0;
+        if (a.host_flags) a.host_flags[q] = flag ? 1 : 0;
         a.arrivals[q] = 0;
         if (flag) atomicAdd(a.fallback_counter, 1ull);
         else if (extended) atomicAdd(a.extend_counter, 1ull);
@@ -1359,6 +1361,10 @@ struct DenseIndex {
     static constexpr int kSlots = 8;   // launches in flight: the scan of step i+1 runs beside the tails of steps i, i-1, ...
     Workspace ws[kSlots];
     DevBuf qbuf, o64, o32, oid;
+    // pinned host staging of hipidx_search's few-query path (device-visible under the same address): the query goes up with
+    // an asynchronous copy, the finish writes scores, ids and flags straight into host memory
+    PinBuf pin_q, pin_o32, pin_oid, pin_flags;
+    static constexpr int kFewQueries = 16;
     int launch_q = 256;       // queries one begin/finish pair takes (a multiple of 64): update_launch_q
     int launch_env = 0;       // HIPRAG_LAUNCH_QUERIES (0 = size launches by the index)
     // stats
@@ -1621,8 +1627,12 @@ struct DenseIndex {
     }
 
     // phase 2: the finish (list ranking, fp64 re-score, extension, certificate) + the exhaustive path; reads workspace `slot`
+    // host_flags (pinned host memory, nq ints) != null: the finish also writes the queries' flags there and the exhaustive
+    // check is NOT launched -- the caller synchronises, looks at the flags and calls exhaustive_pass only if one is set
+    // (hipidx_search's few-query path: one launch and one kernel's run time less on the way to the host)
     template <int METRIC>
-    int32_t finish_pass(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    int32_t finish_pass(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st,
+                        int* host_flags = nullptr)
     {
         Workspace& w = ws[slot];
         const int64_t nb = nblocks();
@@ -1631,7 +1641,7 @@ struct DenseIndex {
         if (nb > 0 && fast_k(k)) {
             FinArgs fa;
             fa.xb = xb.as<float4>(); fa.q = q_dev; fa.max_norm2_bits = max_norm2_bits();
-            fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp; fa.flags = flags; fa.arrivals = arrivals;
+            fa.out64 = o64p; fa.out32 = o32p; fa.out_ids = oidp; fa.flags = flags; fa.host_flags = host_flags; fa.arrivals = arrivals;
             fa.fallback_counter = fallback_counter(); fa.extend_counter = extend_counter(); fa.work_counters = work_counters();
             fa.slots = st_slots(w); fa.thetac = st_thetac(w); fa.count = st_count(w);
             fa.list = w.list.as<Cand>();
@@ -1641,8 +1651,18 @@ struct DenseIndex {
             w.dirty = false;
         } else {
             hipLaunchKernelGGL(flag_all_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, flags, arrivals, fallback_counter(), nq);
+            host_flags = nullptr;   // every query is flagged: nothing to look at first
         }
+        if (host_flags) { HR_CHECK_HIP(hipGetLastError()); return HIPRAG_OK; }
+        return exhaustive_pass<METRIC>(q_dev, nq, k, slot, o64p, o32p, oidp, st);
+    }
 
+    template <int METRIC>
+    int32_t exhaustive_pass(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        Workspace& w = ws[slot];
+        int* flags = w.flags.as<int>();
+        int* arrivals = flags + w.q;
         ExArgs ea;
         ea.xb = xb.as<float4>(); ea.q = q_dev; ea.flags = flags; ea.arrivals = arrivals;
         ea.ek = w.ek.as<u64>(); ea.ei = w.ei.as<i64>();
@@ -1684,10 +1704,52 @@ struct DenseIndex {
                                           : scan_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, st);
     }
 
-    int32_t finish_dev(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    int32_t finish_dev(const float* q_dev, int nq, int k, int slot, double* o64p, float* o32p, int64_t* oidp, hipStream_t st,
+                       int* host_flags = nullptr)
     {
-        return metric == HIPRAG_METRIC_IP ? finish_pass<HIPRAG_METRIC_IP>(q_dev, nq, k, slot, o64p, o32p, oidp, st)
-                                          : finish_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, o64p, o32p, oidp, st);
+        return metric == HIPRAG_METRIC_IP ? finish_pass<HIPRAG_METRIC_IP>(q_dev, nq, k, slot, o64p, o32p, oidp, st, host_flags)
+                                          : finish_pass<HIPRAG_METRIC_L2>(q_dev, nq, k, slot, o64p, o32p, oidp, st, host_flags);
+    }
+
+    // hipidx_search for a handful of queries (the reference's call shape: ONE, rag/storage/faiss_index.py:81-83): what is
+    // not the scan has to be short.  Query up through pinned staging with an asynchronous copy; the finish writes scores,
+    // ids and its flags straight into pinned host memory; one synchronise; the exhaustive check is launched only if the
+    // finish flagged a query (it almost never does) -- against the general path: two blocking D2H copies, one blocking H2D
+    // copy and one kernel less between the scan and the caller.
+    int32_t search_few_host(const float* q_host, int nq, int k, float* out_scores, int64_t* out_ids)
+    {
+        int32_t rc;
+        const size_t nk = (size_t)nq * k;
+        if ((rc = qbuf.reserve((size_t)nq * d * sizeof(float)))) return rc;
+        if ((rc = o64.reserve(nk * sizeof(double)))) return rc;
+        if ((rc = pin_q.reserve((size_t)nq * d * sizeof(float)))) return rc;
+        if ((rc = pin_o32.reserve(nk * sizeof(float)))) return rc;
+        if ((rc = pin_oid.reserve(nk * sizeof(int64_t)))) return rc;
+        if ((rc = pin_flags.reserve((size_t)nq * sizeof(int)))) return rc;
+        if ((rc = prepare(k, 0))) return rc;
+        memcpy(pin_q.p, q_host, (size_t)nq * d * sizeof(float));
+        HR_CHECK_HIP(hipMemcpyAsync(qbuf.p, pin_q.p, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, nullptr));
+        int* hf = reinterpret_cast<int*>(pin_flags.p);
+        float* h32 = reinterpret_cast<float*>(pin_o32.p);
+        int64_t* hid = reinterpret_cast<int64_t*>(pin_oid.p);
+        if ((rc = begin_dev(qbuf.as<float>(), nq, k, 0, nullptr))) return rc;
+        for (int i = 0; i < nq; ++i) hf[i] = 1;   // a finish that does not write them (k beyond the fast path) launches the check itself
+        if ((rc = finish_dev(qbuf.as<float>(), nq, k, 0, o64.as<double>(), h32, hid, nullptr, hf))) return rc;
+        HR_CHECK_HIP(hipStreamSynchronize(nullptr));
+        if (nblocks() > 0 && fast_k(k)) {
+            int any = 0;
+            for (int i = 0; i < nq; ++i) any |= hf[i];
+            if (any) {
+                rc = metric == HIPRAG_METRIC_IP
+                         ? exhaustive_pass<HIPRAG_METRIC_IP>(qbuf.as<float>(), nq, k, 0, o64.as<double>(), h32, hid, nullptr)
+                         : exhaustive_pass<HIPRAG_METRIC_L2>(qbuf.as<float>(), nq, k, 0, o64.as<double>(), h32, hid, nullptr);
+                if (rc) return rc;
+                HR_CHECK_HIP(hipStreamSynchronize(nullptr));
+            }
+        }
+        memcpy(out_scores, h32, nk * sizeof(float));
+        memcpy(out_ids, hid, nk * sizeof(int64_t));
+        return HIPRAG_OK;
     }
 
     int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
@@ -1982,6 +2044,7 @@ int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, fl
     if (nq == 0) return HIPRAG_OK;
     HR_REQUIRE(q_host && out_scores && out_ids, "null pointer");
     int32_t rc;
+    if (nq <= DenseIndex::kFewQueries) return ix->search_few_host(q_host, nq, k, out_scores, out_ids);
     if ((rc = ix->qbuf.reserve((size_t)nq * ix->d * sizeof(float)))) return rc;
     if ((rc = ix->o64.reserve((size_t)nq * k * sizeof(double)))) return rc;
     if ((rc = ix->o32.reserve((size_t)nq * k * sizeof(float)))) return rc;

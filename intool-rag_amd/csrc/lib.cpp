@@ -69,7 +69,7 @@ static ScanStreams& scan_streams()
     static ScanStreams s;
     return s;
 }
-constexpr int kHybridSpareCus = 80;   // of 256: dense top-50 alone loses 0-2 % on 176 workgroups, BM25 keeps up on 80 CUs (config 2)
+constexpr int kHybridSpareCus = 96;   // of 256: dense top-50 alone loses 0-7 % on 160 workgroups; 64-112 measure within the box-to-box spread (config 2)
 
 // The two events of one hybrid call (legs start / dense leg done), pooled per device.
 struct LegEvents {

@@ -31,7 +31,7 @@ from .index import HipFlatIndex, merge_topk_device
 
 N_SLOTS = 8     # library workspace slots = passes that may be in flight (DenseIndex::kSlots)
 SPARE_CUS = 48          # CUs a flat scan leaves to the tails of earlier launches (of 256; 32-64 measure the same)
-SPARE_CUS_HYBRID = 80   # ... when the tails include the BM25 leg (lib.cpp kHybridSpareCus)
+SPARE_CUS_HYBRID = 96   # ... when the tails include the BM25 leg (lib.cpp kHybridSpareCus)
 
 
 def _scan_stream(device):

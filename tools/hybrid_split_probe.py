@@ -117,6 +117,33 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
+    from collections import deque
+    from hiprag.sharded import ShardedHybrid
+    gq2 = torch.Generator(device=dev)
+    gq2.manual_seed(999)
+    many = torch.randn((2048, d), generator=gq2, device=dev)
+    many /= many.norm(dim=1, keepdim=True)
+    sq_many = [sq[i % nq] for i in range(2048)]
+
+    def pipelined(sh, batch, steps=24):
+        def run(n):
+            pending = deque()
+            last = None
+            for i in range(n):
+                o = (i * batch) % 2048
+                pending.append(sh.search_begin(many[o:o + batch], sq_many[o:o + batch], depth, k))
+                if len(pending) >= 4:
+                    last = sh.search_end(pending.popleft())
+            while pending:
+                last = sh.search_end(pending.popleft())
+            return last
+        run(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        return steps * batch / (time.perf_counter() - t0)
+
     ref = hybrid(False)
     torch.cuda.synchronize()
     ref = (ref[0].clone(), ref[1].clone())
@@ -131,6 +158,10 @@ def main():
         t_hp = timed(hybrid_hp)
         t_hpm = timed(hybrid_hp_main)
         t_prod = timed(lambda: hybrid_search_device(index, bm25, queries, sq, depth=depth, k=k))
+        sh = ShardedHybrid(index, bm25)
+        index.set_spare_cus(spare)
+        pipe = {f"pipelined_{b}_per_step_qps": round(pipelined(sh, b), 1) for b in (256, 512)}
+        print(json.dumps({"spare_cus": spare, **pipe}), flush=True)
         index.set_spare_cus(spare)
         got = hybrid(True)
         torch.cuda.synchronize()
