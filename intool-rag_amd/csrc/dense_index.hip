@@ -232,6 +232,12 @@ struct ScanArgs {
     int filter;           // 0: list every group (small indexes)
     int ncls;             // theta classes in use: min(kClasses, waves that own blocks) -- every class needs a publisher, or theta never forms
     unsigned long long* stamps;  // timing only (else null): [waves][2] wall-clock ticks at wave entry / exit
+    // start gate (hipidx_gate_tail_dev): every workgroup counts itself in when it starts; the one that completes the launch
+    // (started == target: every workgroup of the grid holds its CU) writes the launch's sequence number into the signal word
+    // the tail streams of the PREVIOUS launch wait on
+    unsigned long long* started;
+    unsigned long long target, seq;
+    unsigned long long* gate;     // signal memory, or null
 };
 
 __host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks, int64_t nwaves)
@@ -649,6 +655,10 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     const int S = nbw * (PIECES_PER_BLOCK);                                                                              \
     const float4* base = (BASE_PTR);                                                                                     \
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();                                                        \
+    if (a.gate && tid == 0) {                                                                                            \
+        const unsigned long long was = __hip_atomic_fetch_add(a.started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        if (was + 1 == a.target) __hip_atomic_fetch_max(a.gate, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      \
+    }                                                                                                                    \
     TailLds L;                                                                                                           \
     L.stage = reinterpret_cast<Cand*>(reinterpret_cast<char*>(qs) + (size_t)a.P * 1024);                                 \
     L.ctl = reinterpret_cast<u32*>(L.stage + 2 * kStageHalf);                                                            \
@@ -1357,6 +1367,7 @@ struct DenseIndex {
         int ev_idx = -1;
         bool dirty = false;                  // a scan ran without its finish: the scan state is not clean
         int waves = 8;
+        unsigned long long seq = 0;          // sequence number of the scan last launched into this slot (0: none)
     };
     static constexpr int kSlots = 8;   // launches in flight: the scan of step i+1 runs beside the tails of steps i, i-1, ...
     Workspace ws[kSlots];
@@ -1364,6 +1375,11 @@ struct DenseIndex {
     // pinned host staging of hipidx_search's few-query path (device-visible under the same address): the query goes up with
     // an asynchronous copy, the finish writes scores, ids and flags straight into host memory
     PinBuf pin_q, pin_o32, pin_oid, pin_flags;
+    // start gate: see ScanArgs.  `gate` is signal memory (hipMallocSignalMemory: what hipStreamWaitValue64 may wait on),
+    // `started` a device counter; both only ever grow.
+    unsigned long long* gate = nullptr;
+    DevBuf started;
+    unsigned long long scan_seq = 0, started_total = 0;
     static constexpr int kFewQueries = 16;
     int launch_q = 256;       // queries one begin/finish pair takes (a multiple of 64): update_launch_q
     int launch_env = 0;       // HIPRAG_LAUNCH_QUERIES (0 = size launches by the index)
@@ -1405,6 +1421,7 @@ struct DenseIndex {
 
     ~DenseIndex()
     {
+        if (gate) (void)hipFree(gate);
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
         if (add_ev) (void)hipEventDestroy(add_ev);
     }
@@ -1426,6 +1443,17 @@ struct DenseIndex {
         update_launch_q();
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
+        if ((rc = started.reserve(64))) return rc;
+        HR_CHECK_HIP(hipMemset(started.p, 0, 64));
+        {
+            void* g = nullptr;
+            if (hipExtMallocWithFlags(&g, 8, hipMallocSignalMemory) == hipSuccess && g) {
+                gate = reinterpret_cast<unsigned long long*>(g);
+                HR_CHECK_HIP(hipMemset(g, 0, 8));
+            } else {
+                (void)hipGetLastError();   // no signal memory: tails are not gated (hipidx_gate_tail_dev does nothing)
+            }
+        }
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
         HR_CHECK_HIP(hipStreamSynchronize(nullptr));   // hipMemset of device memory may return before the fill has run
         return HIPRAG_OK;
@@ -1585,6 +1613,7 @@ struct DenseIndex {
         // launch only (the in-kernel stamps cover every launch either way)
         const bool use_ev = timing && ev_count % ev_every == 0;
         const bool run_scan = nb > 0 && fast_k(k);   // deeper k: every query takes the exhaustive path, nothing to scan for
+        w.seq = 0;
         if (run_scan) {
             if (w.dirty) HR_CHECK_HIP(hipMemsetAsync(w.state.p, 0, w.state.bytes, st));   // a scan without its finish came before
             w.dirty = true;
@@ -1600,6 +1629,9 @@ struct DenseIndex {
             sa.ncls = (int)std::max<int64_t>(1, std::min<int64_t>(kClasses, (nb + bpw - 1) / bpw));   // waves that own blocks
             if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2, 0, (size_t)n_cu * kMaxScanWaves * 16, st));
             sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2 : nullptr;
+            w.seq = ++scan_seq;
+            started_total += (unsigned long long)scan_cus;
+            sa.started = started.as<unsigned long long>(); sa.target = started_total; sa.seq = w.seq; sa.gate = gate;
             const size_t scan_lds = (size_t)P * 1024 + (size_t)2 * kStageHalf * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
             const bool one_pass = nq <= kPassQ;
             void (*scan)(ScanArgs);
@@ -1977,6 +2009,18 @@ int32_t hipidx_set_spare_cus(uint64_t h, int32_t n)
     // takes effect with the next launch: the finish reads a launch's lists and bounds, never its partition, and the stamp
     // buffer is sized for the whole chip
     ix->scan_cus = ix->n_cu - n;
+    return HIPRAG_OK;
+}
+
+int32_t hipidx_gate_tail_dev(uint64_t h, int32_t slot, void* stream)
+{
+    GET_INDEX(h);
+    HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
+    const unsigned long long seq = ix->ws[slot].seq;
+    if (!ix->gate || seq == 0) return HIPRAG_OK;
+    // only a scan that is already on its way can open the gate: a wait for one that may never be launched would hang the stream
+    HR_REQUIRE(ix->scan_seq > seq, "hipidx_gate_tail_dev: no scan has been launched after the one of slot %d", slot);
+    HR_CHECK_HIP(hipStreamWaitValue64((hipStream_t)stream, ix->gate, seq + 1, hipStreamWaitValueGte, ~0ull));
     return HIPRAG_OK;
 }
 

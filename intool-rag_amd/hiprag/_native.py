@@ -73,6 +73,7 @@ SIGNATURES = {
     "hipidx_launch_queries": [c_uint64, i32p],
     "hipidx_set_spare_cus": [c_uint64, c_int32],
     "hipidx_get_spare_cus": [c_uint64, c_void_p],
+    "hipidx_gate_tail_dev": [c_uint64, c_int32, c_void_p],
     "hipidx_reserve_search": [c_uint64, c_int32],
     "hipidx_reserve_rows": [c_uint64, c_int64],
     "hipidx_reconstruct": [c_uint64, c_int64, c_void_p],

@@ -137,6 +137,11 @@ class HipFlatIndex:
         RCCL all-gather); takes effect with the next launch.  See hipidx_set_spare_cus in hiprag.h."""
         nat.call("hipidx_set_spare_cus", self._h, int(n))
 
+    def gate_tail(self, slot: int, stream: int) -> None:
+        """hipidx_gate_tail_dev: `stream` waits (in the command processor) until the scan launched after the one of `slot` has
+        started -- the finish enqueued behind it then runs on the CUs that scan leaves.  That scan must have been launched."""
+        nat.call("hipidx_gate_tail_dev", self._h, int(slot), ctypes.c_void_p(stream))
+
     @property
     def spare_cus(self) -> int:
         n = ctypes.c_int32()

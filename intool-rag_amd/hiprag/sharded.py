@@ -149,6 +149,7 @@ class ShardedFlatIndex:
         self.side = _slot_streams(local.device)
         self._side_ptr = [st.cuda_stream for st in self.side]
         self._slot = 0
+        self._pending = None          # slot of the step whose tails have not been enqueued yet (at most one: the newest)
         self._slot_used = [False] * N_SLOTS
         self._slot_ended = [False] * N_SLOTS
         self._bufs = [dict() for _ in range(N_SLOTS)]
@@ -221,16 +222,35 @@ class ShardedFlatIndex:
             scan.wait_event(c["done"])
         self.local.search_begin(q, k, slot, stream=scan.cuda_stream)
         c["scanned"].record(scan)
-        side.wait_event(c["scanned"])
         self._slot_used[slot] = True
         self._slot_ended[slot] = False
+        # The tails of the PREVIOUS step are enqueued only now, behind a gate that the scan just launched opens when it has
+        # STARTED (hipidx_gate_tail_dev): they are dispatched onto the CUs this scan leaves instead of racing it for CUs --
+        # both become ready at the same moment, and which queue the hardware serves first depends on things no host controls.
+        # This step's own tails wait for the next search_begin, or for its search_end, whichever comes first.
+        self._flush_tails(gated=True)
+        c["work"], c["q"] = None, q
+        self._pending = slot
+        return (None, slot, k)
+
+    def _flush_tails(self, gated: bool) -> None:
+        """Enqueue the tails (finish -> all-gather) of the step whose scan was launched last, if they are still due."""
+        import torch
+        slot = self._pending
+        if slot is None:
+            return
+        self._pending = None
+        c = self._bufs[slot]
+        side, pack = self.side[slot], c["pack"]
+        q, k = c["q"], c["key"][1]
+        side.wait_event(c["scanned"])
+        if gated:
+            self.local.gate_tail(slot, self._side_ptr[slot])
         self.local.search_finish(q, k, slot, (pack[0].view(torch.float64), c["s32"], pack[1]), stream=self._side_ptr[slot])
         c["done"].record(side)
-        work = None
         if self.exchange:
             with torch.cuda.stream(side):
-                work = self.gather(pack, c["gathered"], self.group, async_op=True)
-        return (work, slot, k)
+                c["work"] = self.gather(pack, c["gathered"], self.group, async_op=True)
 
     def search_end(self, ticket, wait: bool = True):
         """-> (scores64, scores32, ids) [nq,k].  With wait=True (default) the caller's current stream is made to wait
@@ -240,6 +260,10 @@ class ShardedFlatIndex:
         work, slot, k = ticket
         c = self._bufs[slot]
         main = torch.cuda.current_stream()
+        if self.tails_aside:
+            if self._pending == slot:
+                self._flush_tails(gated=False)     # no scan has been launched behind this step's: nothing to wait for
+            work = c["work"]
         self._slot_ended[slot] = wait or not self.tails_aside
         if work is None:
             if self.tails_aside:
@@ -260,6 +284,8 @@ class ShardedFlatIndex:
     def result_event(self, ticket):
         """Event that completes when the results of `ticket` are final (after search_end)."""
         work, slot, _ = ticket
+        if self.tails_aside:
+            work = self._bufs[slot].get("work")
         if work is None and not self.tails_aside:
             import torch
             ev = torch.cuda.Event()

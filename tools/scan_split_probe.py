@@ -21,11 +21,21 @@ def main():
     from hiprag.sharded import ShardedFlatIndex
     dev = torch.device("cuda", 0)
     rows, k, d = int(os.environ.get("ROWS", 1_000_000)), int(os.environ.get("K", 10)), 1024
+    pre = os.environ.get("PRE", "none")          # a large torch allocation BEFORE the index buffers: none | keep | free
+    chunk = int(os.environ.get("CHUNK", 125000))  # rows per add
+    dummy = None
+    if pre != "none":
+        dummy = torch.empty(int(os.environ.get("PRE_MB", 512)) << 20, dtype=torch.uint8, device=dev)
+        if pre == "free":
+            del dummy
+            torch.cuda.empty_cache()
     ix = HipFlatIndex(d, os.environ.get("METRIC", "ip"))
-    for c in range(0, rows, 125000):
+    if os.environ.get("RESERVE") == "1":
+        ix.reserve_rows(rows)
+    for c in range(0, rows, chunk):
         g = torch.Generator(device=dev)
-        g.manual_seed(1234 + c // 125000)
-        x = torch.randn((min(125000, rows - c), d), generator=g, device=dev)
+        g.manual_seed(1234 + c // chunk)
+        x = torch.randn((min(chunk, rows - c), d), generator=g, device=dev)
         x /= x.norm(dim=1, keepdim=True)
         ix.add_device(x)
     del x
@@ -37,6 +47,12 @@ def main():
     batch = ix.launch_queries
     nb = queries.shape[0] // batch
     ref = None
+    skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("SKIP_STREAMS", 0)))]   # dummy streams created first
+    if os.environ.get("USE_SKIPPED") == "1":
+        for st_ in skipped:
+            with torch.cuda.stream(st_):
+                torch.zeros(8, device=dev)
+        torch.cuda.synchronize()
     tail_prio = os.environ.get("TAIL_PRIO")      # priority of the tail streams (HIP: -1 high, 0 normal, 1 low)
     tails = []
     if tail_prio is not None:
@@ -53,8 +69,27 @@ def main():
     if os.environ.get("SCAN_PRIO") == "high":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     for spare in [int(s) for s in os.environ.get("SPARES", "0,16,32,48,64,96").split(",")]:
-        for aside in (False, True):
+        for aside in ((True,) if os.environ.get("ASIDE_ONLY") == "1" else (False, True)):
             sh = ShardedFlatIndex(ix, 0, tails_aside=aside)
+            layout = os.environ.get("CU_MASK")       # interleaved | blocked: scan and tail streams on disjoint CU sets
+            if aside and layout:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                ncu = 256
+                tail_bits = [i for i in range(ncu) if ((i // 8) >= (ncu - spare) // 8 if layout == "interleaved" else i >= ncu - spare)]
+                def mk(bits):
+                    words = (ctypes.c_uint32 * (ncu // 32))()
+                    for b in bits:
+                        words[b // 32] |= (1 << (b % 32))
+                    st = ctypes.c_void_p()
+                    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ncu // 32, words)
+                    assert rc == 0, rc
+                    return torch.cuda.ExternalStream(st.value, device=dev)
+                scan_bits = [i for i in range(ncu) if i not in set(tail_bits)]
+                sh.scan = mk(scan_bits)
+                tails2 = [mk(tail_bits), mk(tail_bits)]
+                sh.side = [tails2[i % 2] for i in range(len(sh.side))]
+                sh._side_ptr = [st.cuda_stream for st in sh.side]
             if aside and tail_prio is not None:
                 sh.side = [tails[i % 2] for i in range(len(sh.side))]
                 sh._side_ptr = [st.cuda_stream for st in sh.side]
