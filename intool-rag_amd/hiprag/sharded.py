@@ -19,8 +19,11 @@ with equal priorities the finish's many small workgroups are placed first, on ev
 need an EMPTY CU) start late and unevenly -- measured 2.68-2.87 ms per launch against 2.49 alone, which is why rounds 1-2
 ran the finish in stream order on one GPU.  With the scan served first: 1M rows 194.7 -> 199.5 k queries/s, 500 k rows
 374 -> 385 k, 125 k rows (the 8-GPU share) 1.09 -> 1.22 M, same box, A/B (`tools/scan_split_probe.py`); the idle time
-between two scans drops from 0.10-0.15 ms to 0.024.  `tails_aside=False` keeps the old arrangement (scan and finish in
-stream order on the caller's stream) for A/B runs.
+between two scans drops from 0.10-0.15 ms to 0.024.  Priority alone still left the outcome to which hardware queues the
+streams happened to get (0.89-1.23 M on the small shard), so the order is explicit: the tails of step i are enqueued when
+scan i + 1 has been launched, behind a gate that scan opens once all its workgroups have started (hipidx_gate_tail_dev);
+a step whose results are wanted before another scan is due gets its tails at search_end, ungated.  `tails_aside=False`
+keeps the old arrangement (scan and finish in stream order on the caller's stream) for A/B runs.
 """
 from __future__ import annotations
 
