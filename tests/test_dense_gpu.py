@@ -467,6 +467,54 @@ def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
         assert np.allclose(s32.cpu().numpy(), es, rtol=0, atol=TOL)
 
 
+def test_start_gate_orders_a_finish_behind_the_start_of_the_next_scan(gpu):
+    """hipidx_gate_tail_dev by hand, the way a C host would use it: scans chained on the library's scan stream, the finish of
+    step i on a tail stream behind (a) the end of scan i and (b) the START of scan i + 1.  The library refuses a gate that
+    nothing would ever open (no scan launched behind the slot's yet) -- a stream waiting for it would hang -- and the gated
+    pipeline returns the oracle's lists."""
+    import ctypes
+    import torch
+    from hiprag import HipFlatIndex, HipRagError
+    from hiprag import _native as nat
+    n, d, k = 30000, 256, 10
+    x = ho.synthetic_vectors(n, d, seed=91)
+    q = ho.synthetic_queries(192, d, seed=92)
+    ix = HipFlatIndex(d, "ip")
+    ix.add(x)
+    ix.set_spare_cus(48)
+    ptr = ctypes.c_void_p()
+    nat.call("hiprag_scan_stream", 0, ctypes.byref(ptr))
+    scan = torch.cuda.ExternalStream(ptr.value)
+    tail = torch.cuda.Stream()
+    qd = torch.from_numpy(q).cuda()
+    torch.cuda.synchronize()
+    outs, scanned = [], []
+    for i in range(3):
+        qi = qd[64 * i:64 * (i + 1)]
+        ix.search_begin(qi, k, slot=i, stream=scan.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(scan)
+        scanned.append(ev)
+        if i == 0:
+            with pytest.raises(HipRagError, match="no scan has been launched after"):
+                ix.gate_tail(0, tail.cuda_stream)
+        else:                                   # the tails of step i - 1, gated on the scan just launched
+            tail.wait_event(scanned[i - 1])
+            ix.gate_tail(i - 1, tail.cuda_stream)
+            out = (torch.empty((64, k), dtype=torch.float64, device="cuda"), torch.empty((64, k), dtype=torch.float32, device="cuda"),
+                   torch.empty((64, k), dtype=torch.int64, device="cuda"))
+            ix.search_finish(qd[64 * (i - 1):64 * i], k, i - 1, out, stream=tail.cuda_stream)
+            outs.append(out)
+    tail.wait_event(scanned[2])                 # the last step: no scan behind it, no gate
+    out = tuple(torch.empty((64, k), dtype=t, device="cuda") for t in (torch.float64, torch.float32, torch.int64))
+    ix.search_finish(qd[128:192], k, 2, out, stream=tail.cuda_stream)
+    outs.append(out)
+    torch.cuda.synchronize()
+    _, ei = ho.flat_search(x, q, k, ho.METRIC_IP)
+    got = np.concatenate([o[2].cpu().numpy() for o in outs])
+    assert np.array_equal(got, ei)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "q64"])
 def test_near_ties_below_the_scan_resolution_stay_exact(gpu, monkeypatch, mode):
     """Adversarial for the certificate: 3000 rows that differ from each other by 1e-6 .. 1e-4 relative -- far below what

@@ -69,12 +69,14 @@ def main():
     qv = enc.encode_tokens(toks, batch_size=args.nq)
     sync()
     t_embed = time.perf_counter() - t0
+    from hiprag import hybrid_search_device
+    hybrid_search_device(index, bm25, qv[:8], sparse_q[:8], depth=50, k=args.k)      # workspaces and staging exist
+    sync()
     t0 = time.perf_counter()
-    d = index.search_device(qv, 50)
-    s = bm25.search_device(sparse_q, 50)
-    fs, fi = rrf_fuse_device(d[2], s[2], args.k)
+    fs, fi, ((d64, dids), (s64, sids)) = hybrid_search_device(index, bm25, qv, sparse_q, depth=50, k=args.k, return_lists=True)
     sync()
     t_retr = time.perf_counter() - t0
+    d, s = (d64, None, dids), (s64, s64.to(torch.float32), sids)
     nr = min(args.rerank_queries, args.nq)
     fused = fi[:nr].cpu().numpy()
     pairs = []

@@ -20,12 +20,12 @@ def main():
     import torch
     from hiprag import HipBM25, HipFlatIndex, build_postings, rrf_fuse_device
     dev = torch.device("cuda", 0)
-    N, V, d, nq, depth, k = 1_000_000, 262144, 1024, 256, 50, 10
+    N, V, d, nq, depth, k = int(os.environ.get("DOCS", 1_000_000)), 262144, 1024, 256, 50, 10
     index = HipFlatIndex(d, "ip")
     for c in range(0, N, 125000):
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + c // 125000)
-        x = torch.randn((125000, d), generator=g, device=dev)
+        x = torch.randn((min(125000, N - c), d), generator=g, device=dev)
         x /= x.norm(dim=1, keepdim=True)
         index.add_device(x)
     del x
