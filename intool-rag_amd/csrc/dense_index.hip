@@ -1015,7 +1015,7 @@ __device__ __forceinline__ void write_result(double* out64, float* out32, int64_
 constexpr int kListLds = kNoFilterGroups;   // groups of one query the finish ranks in LDS
 constexpr int kMaxRescore = 192;            // groups re-scored (tagged quads) per query
 constexpr int kMaxExpand = 24;              // groups whose other three quads are re-scored
-constexpr int kFinThreads = 512;            // 8 waves and <= 40 KiB of LDS: four workgroups per CU, so the 1024 queries of a small-shard
+constexpr int kFinThreads = 512;            // 8 waves and <= 40 KiB of LDS, two workgroups per CU (see fin_kernel): the 1024 queries of a small-shard
                                             // launch are finished in ONE round of workgroups (16 waves / 55 KiB: two rounds, 0.14 ms)
 constexpr int kCandRows = 4 * kMaxRescore + 12 * kMaxExpand;
 constexpr int kMaxKFast = 128;              // deepest k of this path; beyond: exhaustive path for every query
@@ -1042,7 +1042,11 @@ struct FinArgs {
 };
 
 template <int METRIC>
-__global__ __launch_bounds__(kFinThreads) void fin_kernel(FinArgs a)
+// (kFinThreads, 4): four waves per SIMD, i.e. TWO of these 8-wave workgroups per CU.  Left alone the compiler takes 142
+// VGPRs -- three waves per SIMD, ONE workgroup per CU -- and a finish workgroup is a ~0.15 ms chain of dependent steps
+// that only other workgroups on the CU can hide: on the CUs the next scan leaves it the finish of 1024
+// queries then lasted as long as the scan itself.  128 VGPRs cost 36 bytes of scratch per lane.
+__global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
 {
     __shared__ float qv[kMaxDPad];
     // the unsorted list (lkey / lsec) is dead once it has been ranked into skey / ssec: the re-scored rows (ck / ci) overlay it
