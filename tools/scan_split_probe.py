@@ -95,14 +95,21 @@ def main():
                 sh._side_ptr = [st.cuda_stream for st in sh.side]
             ix.set_spare_cus(spare)
 
+            host = {"begin": 0.0, "end": 0.0, "n": 0}
+
             def steps(n, first=0):
                 pending = deque()
                 last = None
                 for s in range(n):
                     b = (first + s) % nb
+                    h0 = time.perf_counter()
                     pending.append(sh.search_begin(queries[b * batch:(b + 1) * batch], k))
+                    h1 = time.perf_counter()
+                    host["begin"] += h1 - h0
+                    host["n"] += 1
                     if len(pending) >= 4:
                         last = sh.search_end(pending.popleft())
+                        host["end"] += time.perf_counter() - h1
                 while pending:
                     last = sh.search_end(pending.popleft())
                 return last
@@ -125,7 +132,9 @@ def main():
             print(json.dumps({"rows": rows, "k": k, "batch": batch, "spare_cus": spare, "finish_beside_next_scan": aside,
                               "qps": round(n * batch / el, 1), "ms_per_step": round(el / n * 1e3, 4),
                               "scan_ms": round(st["avg_scan_ms"], 4), "scan_ms_gpu_clock": round(st["avg_scan_wall_ms"], 4),
-                              "gap_ms": round(st["avg_scan_gap_ms"], 4), "ids_equal": bool(torch.equal(ids, ref))}), flush=True)
+                              "gap_ms": round(st["avg_scan_gap_ms"], 4), "ids_equal": bool(torch.equal(ids, ref)),
+                              "host_ms_per_step_in_begin": round(host["begin"] / max(1, host["n"]) * 1e3, 4),
+                              "host_ms_per_step_in_end": round(host["end"] / max(1, host["n"]) * 1e3, 4)}), flush=True)
 
 
 if __name__ == "__main__":
