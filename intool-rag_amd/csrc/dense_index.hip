@@ -221,6 +221,7 @@ struct ScanArgs {
     const float4* xb;     // blocked fp32 rows (q64 mode)
     const void* xh;       // bf16 filter copy (bf16 mode)
     const float* q;       // [nq, d] row-major queries
+    const void* qtile;    // bf16 mode, multi-pass launches: the passes' LDS tile images, made by qtile_kernel (else null)
     const float* norms;   // [rows] squared norms (L2 only)
     u32* slots;           // [passes][kClasses][64]: published chunk maxima (ord32 images), query = 64 * pass + lane
     u32* thetac;          // [Q] current bound per query (ord32 image; 0 = none yet)
@@ -616,6 +617,54 @@ __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, 
     }
 }
 
+// The same tile images for EVERY pass of a launch, written once by a small kernel ahead of the scan (multi-pass launches of
+// the bf16 kernel): out[pass][idx] = what stage_query_tile puts at qw[idx] for qbase = 64 pass.  The scan's workgroups then
+// copy a finished 128 KiB image per pass instead of each converting it from the fp32 queries: with 512 threads the
+// conversion was four dependent L2 round trips per pass, with the 256 threads of a small-shard workgroup eight -- 10 us of
+// a 50 us pass at 125 k rows per GPU, sixteen times per launch.
+__global__ __launch_bounds__(256) void qtile_kernel(const float* __restrict__ q, int nq, int d, int P2, bf16x8* __restrict__ out)
+{
+    const int per_pass = 2 * P2 * 64;
+    const int pass = blockIdx.y, qbase = pass * 64;
+    const bool vec_ok = (d & 3) == 0;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per_pass; idx += gridDim.x * 256) {
+        const int tile = idx >= P2 * 64;
+        const int u = idx - tile * P2 * 64;
+        const int p = u >> 6, l = u & 63;
+        const int b = qbase + (l & 31) + 32 * tile;
+        const int col = 16 * p + 8 * (l >> 5);
+        float v[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = col + 4 * half;
+            if (b < nq && vec_ok && c + 3 < d) {
+                const float4 t = *reinterpret_cast<const float4*>(q + (int64_t)b * d + c);
+                v[4 * half + 0] = t.x; v[4 * half + 1] = t.y; v[4 * half + 2] = t.z; v[4 * half + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * half + j] = (b < nq && c + j < d) ? q[(int64_t)b * d + c + j] : 0.f;
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+        out[(size_t)pass * per_pass + idx] = o;
+    }
+}
+
+// copy of one pass's image into LDS by LDS-DMA: a wave instruction moves 64 consecutive 16-B fragments (1 KiB, lane-linear on
+// both sides), every wave issues its whole share before anyone waits -- one round trip per pass, no registers
+typedef __attribute__((address_space(3))) void* scan_lds_ptr_t;
+template <int NT>
+__device__ __forceinline__ void stage_query_tile_image(const bf16x8* __restrict__ img, bf16x8* qw, int P2, int tid)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nchunks = 2 * P2;                       // 1 KiB chunks in the image
+    for (int c = wave; c < nchunks; c += NT / 64)
+        __builtin_amdgcn_global_load_lds((const void*)(img + (size_t)c * 64 + lane), (scan_lds_ptr_t)(qw + (size_t)c * 64), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the image has landed (and, in order before it, whatever the ring had in flight)
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K1, the two operand modes (HIPRAG_SCAN_MODE).  Both answer 64 queries per pass against bf16 query tiles, run
 // ceil(nq / 64) passes back to back inside one launch (barrier, re-stage the tile, stream the wave's block range again; the
@@ -718,7 +767,9 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_bf16_kernel(ScanArgs a)
     const bf16x8* q0 = reinterpret_cast<const bf16x8*>(qs);
     const bf16x8* q1 = q0 + P2 * 64;
     for (int pass = 0; pass < npass; ++pass) {
-        HIPRAG_PASS_PROLOGUE(stage_query_tile<NT>(a, reinterpret_cast<bf16x8*>(qs), P2, qbase, tid));
+        HIPRAG_PASS_PROLOGUE(if (MULTI && a.qtile) stage_query_tile_image<NT>(reinterpret_cast<const bf16x8*>(a.qtile) + (size_t)pass * 2 * P2 * 64,
+                                                                             reinterpret_cast<bf16x8*>(qs), P2, tid);
+                             else stage_query_tile<NT>(a, reinterpret_cast<bf16x8*>(qs), P2, qbase, tid));
         if (S <= 0) continue;
 
         int s = 0;
@@ -1366,6 +1417,7 @@ struct DenseIndex {
     // search workspace of one launch in flight
     struct Workspace {
         DevBuf list, state, flags, ek, ei;   // state: count[Q] | thetac[Q] | slots[Q / 64][kClasses][64]
+        DevBuf qtile;                        // bf16 mode: the query-tile images of a multi-pass launch (qtile_kernel)
         int k = 0, q = 0;
         int64_t blocks = 0;
         int ev_idx = -1;
@@ -1594,6 +1646,7 @@ struct DenseIndex {
             HR_CHECK_HIP(hipStreamSynchronize(nullptr));
         }
         if ((rc = w.flags.reserve(2 * Q * sizeof(int)))) return rc;  // flags[Q] + arrivals[Q]
+        if (scan_mode == 3 && (rc = w.qtile.reserve((Q / 64) * (size_t)P * 64 * 16))) return rc;   // passes x (2 * P2 * 64) fragments
         if ((rc = w.ek.reserve(Q * nslices * ekk * sizeof(u64)))) return rc;
         if ((rc = w.ei.reserve(Q * nslices * ekk * sizeof(i64)))) return rc;
         w.k = kk;
@@ -1638,6 +1691,13 @@ struct DenseIndex {
             sa.started = started.as<unsigned long long>(); sa.target = started_total; sa.seq = w.seq; sa.gate = gate;
             const size_t scan_lds = (size_t)P * 1024 + (size_t)2 * kStageHalf * sizeof(Cand) + 64 + (size_t)kThetaBack * 64 * 4;  // query tile + staged appends + control words + bounds
             const bool one_pass = nq <= kPassQ;
+            sa.qtile = nullptr;
+            if (scan_mode == 3 && !one_pass) {
+                const int npass = (nq + kPassQ - 1) / kPassQ, per_pass = P * 64;   // 2 * P2 * 64 fragments of 16 B
+                hipLaunchKernelGGL(qtile_kernel, dim3((unsigned)((per_pass + 255) / 256), (unsigned)npass), dim3(256), 0, st, q_dev, nq, d,
+                                   P / 2, w.qtile.as<bf16x8>());
+                sa.qtile = w.qtile.p;
+            }
             void (*scan)(ScanArgs);
             if (scan_mode == 3) {
                 // ring depth: 16 pieces where that divides the pieces of a block (d_pad / 16), else 8
