@@ -544,8 +544,9 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
 }
 
 // Query tile of one pass in LDS, bf16, for BOTH scan kernels: piece p (16 k-values), lane (h, b): Q^[b][16p + 8h + 0..7] for
-// queries qbase + 0..31, then the same for queries qbase + 32..63 -- the B fragment of v_mfma_f32_32x32x16_bf16.  Every
-// workgroup converts the (L2-resident) row-major fp32 queries itself; there is no preparation launch.
+// queries qbase + 0..31, then the same for queries qbase + 32..63 -- the B fragment of v_mfma_f32_32x32x16_bf16.  This
+// form converts the (L2-resident) row-major fp32 queries in the workgroup: one-pass launches and the q64 kernel; multi-pass
+// launches of the bf16 kernel copy images made by qtile_kernel (below).
 template <int NT>
 __device__ __forceinline__ void stage_query_tile(const ScanArgs& a, bf16x8* qw, int P2, int qbase, int tid)
 {
