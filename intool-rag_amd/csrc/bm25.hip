@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
                                                         const TileSlot* __restrict__ slots, const int* __restrict__ nslots,
                                                         const u32* __restrict__ skip, int max_slots, i64 n_docs, int K1,
                                                         u64* __restrict__ ck, i64* __restrict__ ci, u32* __restrict__ theta,
-                                                        u32* __restrict__ hist, unsigned long long* __restrict__ dbg)
+                                                        u32* __restrict__ hist)
 {
     extern __shared__ float tacc[];  // kTileDocs accumulators
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -108,8 +108,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
     const int q = blockIdx.x, tile = blockIdx.y;
     const u32 tlo = (u32)tile * kTileDocs;
     const u32 tlen = (u32)min((i64)kTileDocs, n_docs - (i64)tlo);
-    unsigned long long* dp = dbg ? dbg + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
-    if (dp && threadIdx.x == 0) dp[0] = wall_clock64();
     // posting ranges of this tile for every slot, resolved up front (slot descriptor -> skip table is a chain of two
     // dependent global loads; done per slot inside the loop it cost ~4 us of latency six times per workgroup)
     __shared__ unsigned long long ra[kMaxSlots], rb[kMaxSlots];
@@ -126,7 +124,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
     }
     for (int i = tid; i < kTileDocs / 4; i += kTileThreads) reinterpret_cast<float4*>(tacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (dp && tid == 0) dp[1] = wall_clock64();
     // The slots form ONE stream of 2048-posting chunks: the loads of the next chunks -- of the same slot or of the next
     // ones -- are in flight while this chunk's accumulator updates run; a workgroup barrier separates slots only.
     constexpr int U = 2048 / kTileThreads;
@@ -211,7 +208,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
     for (int off = 32; off >= 1; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
     if (lane == 0) smax[wv] = wmax;
     __syncthreads();
-    if (dp && tid == 0) dp[2] = wall_clock64();
     float tile_top = 0.f;
 #pragma unroll
     for (int w = 0; w < kTileWaves; ++w) tile_top = fmaxf(tile_top, smax[w]);
@@ -251,7 +247,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
     if (th != 0 && (!(tile_top > 0.f) || th > ord32(tile_top))) {
         const i64 o0 = (((i64)q * gridDim.y + tile) * kTileWaves + wv) * K1;
         if (lane < K1) { ck[o0 + lane] = 0; ci[o0 + lane] = -1; }
-        if (dp && tid == 0) { dp[3] = wall_clock64(); dp[4] = dp[3]; }
         return;
     }
     constexpr int NV = kTileDocs / (kTileWaves * 256);   // float4 per lane: a wave filters its share of the tile
@@ -287,7 +282,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
         }
         if (best) best = wave_bisect_threshold(v, best, top + 1, K1, 10);
     }
-    if (dp && tid == 0) dp[3] = wall_clock64();
     // Survivors: positive accumulators at or above the threshold.  When there are at most 128 of them (the bisection
     // aims at K1 .. 1.5 K1, a bound inherited from other tiles leaves fewer) they are COMPACTED into this wave's own
     // quarter of the tile (its accumulators are in registers by now; no other wave reads that quarter) and RANKED --
@@ -370,7 +364,6 @@ __global__ __launch_bounds__(kTileThreads) void taat_tile_kernel(const u32* __re
         const u64 kth = L.kth(K1);   // this wave holds K1 documents at or above it: publish the bound
         if (lane == 0 && kth != 0) atomicMax(theta + q, (u32)(kth >> 32));
     }
-    if (dp && tid == 0) dp[4] = wall_clock64();
 }
 
 struct FinishArgs {
@@ -410,7 +403,7 @@ struct Bm25Index {
     int device = 0;
     i64 n_docs = 0, n_terms = 0, n_postings = 0, id_base = 0;
     std::vector<uint64_t> offsets;  // host copy: planning happens on the host
-    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, dbg, theta_dev, hist_dev;
+    DevBuf doc_ids, impacts, acc, ranges, ck, ci, o64, o32, oid, skip_dev, slots_dev, nslots_dev, theta_dev, hist_dev;
     std::vector<i64> skip_index;         // per term: first entry of its skip table, or -1 (short lists)
     // Host staging of the query plans: a ring of pinned buffers, each with the event of its last copy.  A call fills the next
     // buffer and enqueues its copies without waiting for anything but THAT buffer's previous copy (kStages calls ago), so a
@@ -473,11 +466,6 @@ struct Bm25Index {
             }
         }
         const i64 lists = ntiles() * kTileWaves;
-        unsigned long long* dbg_p = nullptr;
-        if (getenv("HIPBM25_DEBUG_PHASES")) {
-            if ((rc = dbg.reserve((size_t)nq * ntiles() * 64))) return rc;
-            dbg_p = dbg.as<unsigned long long>();
-        }
         if ((rc = slots_dev.reserve(n_slots * sizeof(TileSlot)))) return rc;
         if ((rc = nslots_dev.reserve((size_t)nq * sizeof(int)))) return rc;
         if ((rc = ck.reserve((size_t)nq * lists * k * sizeof(u64)))) return rc;
@@ -507,21 +495,7 @@ struct Bm25Index {
         auto tile_kernel = n_postings < ((i64)1 << 30) ? taat_tile_kernel<true> : taat_tile_kernel<false>;
         hipLaunchKernelGGL(tile_kernel, dim3(nq, (unsigned)ntiles()), dim3(kTileThreads), kTileDocs * sizeof(float), st,
                            doc_ids.as<u32>(), impacts.as<float>(), slots_dev.as<TileSlot>(), nslots_dev.as<int>(), skip_dev.as<u32>(),
-                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), hist_p, dbg_p);
-        if (dbg_p) {
-            HR_CHECK_HIP(hipStreamSynchronize(st));
-            std::vector<unsigned long long> h((size_t)nq * ntiles() * 8);
-            HR_CHECK_HIP(hipMemcpy(h.data(), dbg_p, h.size() * 8, hipMemcpyDeviceToHost));
-            double ph[4] = {0, 0, 0, 0};
-            unsigned long long t0 = ~0ull, t1 = 0;
-            for (size_t w = 0; w < (size_t)nq * ntiles(); ++w) {
-                for (int p = 0; p < 4; ++p) ph[p] += (double)(h[w * 8 + p + 1] - h[w * 8 + p]);
-                t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 4]);
-            }
-            const double n = (double)nq * ntiles(), us = 1e-2;   // 100 MHz wall clock
-            fprintf(stderr, "[hipbm25] per workgroup (us): ranges+zero %.1f | stream %.1f | threshold %.1f | inserts %.1f ; kernel wall %.1f us, %lld workgroups\n",
-                    ph[0] / n * us, ph[1] / n * us, ph[2] / n * us, ph[3] / n * us, (double)(t1 - t0) * us, (long long)n);
-        }
+                           max_slots, n_docs, k, ck.as<u64>(), ci.as<i64>(), theta_dev.as<u32>(), hist_p);
         const i64 wave_cand = lists * k;
         const i64 per_lane = (wave_cand + 1023) / 1024;
         auto mk = merge_packed_loop_kernel<8>;   // any size

@@ -426,8 +426,8 @@ def test_randomised_shapes_against_the_oracle(gpu, monkeypatch):
             raise AssertionError(f"case {case}: n={n} d={d} k={k} nq={nq} metric={metric} mode={mode}: {e}")
 
 
-@pytest.mark.parametrize("tails", ["in_stream_order", "aside"])
-def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
+@pytest.mark.parametrize("tails", ["in_stream_order", "aside", "aside_one_tail_stream"])
+def test_deep_pipeline_with_changing_batch_shapes(gpu, tails, monkeypatch):
     """Six launches in flight over the eight workspace slots, batch size and k changing from launch to launch (every slot's
     buffers are re-shaped while older launches are still running), in both arrangements of the finish: on the slot streams
     beside later scans, which run on the library's high-priority scan stream (the default), and behind its scan on the
@@ -442,7 +442,9 @@ def test_deep_pipeline_with_changing_batch_shapes(gpu, tails):
     q = ho.synthetic_queries(256, d, seed=72)
     ix = HipFlatIndex(d, "ip")
     ix.add(x)
-    sh = ShardedFlatIndex(ix, 0, tails_aside=(tails == "aside"))
+    if tails == "aside_one_tail_stream":
+        monkeypatch.setenv("HIPRAG_SIDE_STREAMS", "1")         # every slot's tails on ONE stream (default: two, taking turns)
+    sh = ShardedFlatIndex(ix, 0, tails_aside=tails.startswith("aside"))
     qd = torch.from_numpy(q).cuda()
     rng = np.random.default_rng(5)
     plan = [(int(rng.choice([1, 17, 64, 65, 200, 256])), int(rng.choice([1, 10, 50]))) for _ in range(40)]
