@@ -91,6 +91,18 @@ def main():
         main_s.wait_event(ddone)
         return rrf_fuse_device(dense[2], sparse[2], k)
 
+    def hybrid_bm25_then_hp():      # BM25 enqueued first on the caller's stream, then the dense leg on the high-priority stream
+        ready = torch.cuda.Event()
+        ready.record(main_s)
+        hp.wait_event(ready)
+        sparse = bm25.search_device(sq, depth)
+        with torch.cuda.stream(hp):
+            dense = index.search_device(queries, depth)
+            ddone = torch.cuda.Event()
+            ddone.record(hp)
+        main_s.wait_event(ddone)
+        return rrf_fuse_device(dense[2], sparse[2], k)
+
     def hybrid(dense_first):
         ready = torch.cuda.Event()
         ready.record(main_s)
@@ -157,6 +169,7 @@ def main():
         t_bf = timed(lambda: hybrid(False))
         t_hp = timed(hybrid_hp)
         t_hpm = timed(hybrid_hp_main)
+        t_bhp = timed(hybrid_bm25_then_hp)
         t_prod = timed(lambda: hybrid_search_device(index, bm25, queries, sq, depth=depth, k=k))
         sh = ShardedHybrid(index, bm25)
         index.set_spare_cus(spare)
@@ -170,6 +183,7 @@ def main():
                           "hybrid_dense_first_qps": round(nq / t_df, 1), "hybrid_bm25_first_qps": round(nq / t_bf, 1),
                           "hybrid_dense_on_high_priority_stream_qps": round(nq / t_hp, 1), "product_call_qps": round(nq / t_prod, 1),
                           "hybrid_dense_high_priority_bm25_on_callers_stream_qps": round(nq / t_hpm, 1),
+                          "hybrid_bm25_enqueued_first_dense_high_priority_qps": round(nq / t_bhp, 1),
                           "fused_equal_reference": same}), flush=True)
 
 
