@@ -1451,6 +1451,7 @@ struct DenseIndex {
     int64_t ev_count = 0;          // launches since timing was (re)enabled
     int ev_every = 1;
     std::vector<char> ev_set;      // [kEvRing] whether the launch in that ring slot was bracketed by events
+    std::vector<int> ev_waves;     // [kEvRing] waves of that launch (its stamps occupy the first 2 * waves words of the ring slot)
 
     int64_t nblocks() const { return (ntotal + kRowsPerBlock - 1) / kRowsPerBlock; }
     unsigned* max_norm2_bits() { return scalars.as<unsigned>(); }
@@ -1685,7 +1686,8 @@ struct DenseIndex {
             sa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
             const int64_t bpw = scan_blocks_per_wave(nb, (int64_t)scan_cus * nw);
             sa.ncls = (int)std::max<int64_t>(1, std::min<int64_t>(kClasses, (nb + bpw - 1) / bpw));   // waves that own blocks
-            if (timing) HR_CHECK_HIP(hipMemsetAsync(stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2, 0, (size_t)n_cu * kMaxScanWaves * 16, st));
+            // (no fill of the stamp slot ahead of the launch -- a kernel of its own between two scans, 5-15 us: the host knows
+            // how many waves the launch has and reads exactly their words)
             sa.stamps = timing ? stamps.as<unsigned long long>() + (size_t)ev * n_cu * kMaxScanWaves * 2 : nullptr;
             w.seq = ++scan_seq;
             started_total += (unsigned long long)scan_cus;
@@ -1715,7 +1717,7 @@ struct DenseIndex {
             if (use_ev) HR_CHECK_HIP(hipEventRecord(evs[2 * ev + 1], st));
         }
         w.ev_idx = timing ? ev : -1;
-        if (timing) { ev_set[ev] = use_ev && run_scan; ++ev_count; }
+        if (timing) { ev_set[ev] = use_ev && run_scan; ev_waves[ev] = run_scan ? scan_cus * w.waves : 0; ++ev_count; }
         HR_CHECK_HIP(hipGetLastError());
         passes += (nq + kPassQ - 1) / kPassQ;
         ++launches;
@@ -1782,6 +1784,7 @@ struct DenseIndex {
         if (timing && evs.empty()) {
             evs.resize(2 * kEvRing);
             ev_set.assign(kEvRing, 0);
+            ev_waves.assign(kEvRing, 0);
             for (auto& e : evs) HR_CHECK_HIP(hipEventCreate(&e));
             int32_t src = stamps.reserve((size_t)kEvRing * n_cu * kMaxScanWaves * 2 * sizeof(unsigned long long));
             if (src) return src;
@@ -2310,8 +2313,8 @@ int32_t hipidx_get_stats(uint64_t h, hipidx_stats* out)
             std::vector<std::pair<unsigned long long, unsigned long long>> se((size_t)n);
             for (int64_t i = 0; i < n; ++i) {
                 unsigned long long lo = ~0ull, hi = 0;
-                for (size_t w = 0; w < per / 2; ++w) {
-                    if (hst[(size_t)i * per + 2 * w] == 0) continue;   // slot of a wave this launch did not have (zeroed before the launch)
+                const size_t nwaves = std::min<size_t>((size_t)std::max(ix->ev_waves[(size_t)i], 0), per / 2);   // the launch's own waves
+                for (size_t w = 0; w < nwaves; ++w) {
                     lo = std::min(lo, hst[(size_t)i * per + 2 * w]);
                     hi = std::max(hi, hst[(size_t)i * per + 2 * w + 1]);
                 }
