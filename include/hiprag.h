@@ -97,7 +97,12 @@ int32_t hipidx_metric(uint64_t h, int32_t* out_metric);
 int32_t hipidx_set_id_base(uint64_t h, int64_t id_base);
 int32_t hipidx_search(uint64_t h, const float* q_host, int32_t nq, int32_t k, float* out_scores, int64_t* out_ids);
 /* device variant: out_scores64_dev [nq,k] double (exact, for cross-shard merges), out_scores_dev [nq,k]
- * float (may be NULL), out_ids_dev [nq,k] int64. */
+ * float (may be NULL), out_ids_dev [nq,k] int64.  Enqueues and returns; q_dev and the outputs must stay valid until `stream`
+ * has passed the call's work.  A batch of more queries than one launch takes (hipidx_launch_queries) is PIPELINED inside the
+ * library: the scans run back to back on the device's scan stream (hiprag_scan_stream) with 48 CUs left out of their grids,
+ * the finish of every launch but the last beside the next scan (hipidx_gate_tail_dev), `stream` ahead of the first scan
+ * and behind the last finish -- 1M x 1024 rows, 16384 queries per call: 202 k queries/s; a 125 k-row shard: 1.32 M.  Such a
+ * call uses every workspace slot: do not mix it with a begin / finish pipeline in flight on the same index. */
 int32_t hipidx_search_dev(uint64_t h, const float* q_dev, int32_t nq, int32_t k, double* out_scores64_dev,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 /* Queries one scan pass serves: 64.  HIPRAG_SCAN_MODE picks the scan's operands:

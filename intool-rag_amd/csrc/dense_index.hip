@@ -1480,6 +1480,12 @@ struct DenseIndex {
     ~DenseIndex()
     {
         if (gate) (void)hipFree(gate);
+        if (pipe_tail) (void)hipStreamDestroy(pipe_tail);
+        if (pipe_in) (void)hipEventDestroy(pipe_in);
+        for (int i = 0; i < kSlots; ++i) {
+            if (pipe_scanned[i]) (void)hipEventDestroy(pipe_scanned[i]);
+            if (pipe_done[i]) (void)hipEventDestroy(pipe_done[i]);
+        }
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
         if (add_ev) (void)hipEventDestroy(add_ev);
     }
@@ -1852,10 +1858,75 @@ struct DenseIndex {
         return HIPRAG_OK;
     }
 
+    // Streams and events of search_dev's own pipeline (batches of more than one launch): created on first use
+    hipStream_t pipe_tail = nullptr;
+    hipEvent_t pipe_in = nullptr, pipe_scanned[kSlots] = {}, pipe_done[kSlots] = {};
+    static constexpr int kPipeSpareCus = 48;   // hiprag/sharded.py SPARE_CUS: 32-64 measure the same
+
+    int32_t pipe_init()
+    {
+        if (pipe_tail) return HIPRAG_OK;
+        HR_CHECK_HIP(hipStreamCreateWithFlags(&pipe_tail, hipStreamNonBlocking));
+        HR_CHECK_HIP(hipEventCreateWithFlags(&pipe_in, hipEventDisableTiming));
+        for (int i = 0; i < kSlots; ++i) {
+            HR_CHECK_HIP(hipEventCreateWithFlags(&pipe_scanned[i], hipEventDisableTiming));
+            HR_CHECK_HIP(hipEventCreateWithFlags(&pipe_done[i], hipEventDisableTiming));
+        }
+        return HIPRAG_OK;
+    }
+
+    // A batch of several launches, pipelined the way hiprag/sharded.py pipelines steps: the scans chained on the
+    // device's high-priority scan stream with CUs left out of their grids, the finish of launch j on the index's tail stream
+    // behind the end of scan j AND the start of scan j + 1 (the start gate), the last one ungated; `st` -- where the queries
+    // come from and the results are wanted -- is ahead of the first scan and behind the last finish.  Nothing synchronises
+    // the host.  Uses every workspace slot: not to be mixed with a begin / finish pipeline in flight on the same index.
+    int32_t search_dev_pipelined(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
+    {
+        int32_t rc = pipe_init();
+        if (rc) return rc;
+        void* hpv = nullptr;
+        if ((rc = hiprag_scan_stream(device, &hpv))) return rc;
+        hipStream_t hp = (hipStream_t)hpv;
+        HR_CHECK_HIP(hipEventRecord(pipe_in, st));
+        HR_CHECK_HIP(hipStreamWaitEvent(hp, pipe_in, 0));
+        HR_CHECK_HIP(hipStreamWaitEvent(pipe_tail, pipe_in, 0));   // (the output buffers: whatever `st` still does with them is ahead)
+        const int saved_cus = scan_cus;
+        scan_cus = std::min(scan_cus, std::max(1, n_cu - kPipeSpareCus));
+        const int L = (nq + launch_q - 1) / launch_q;
+        auto tails = [&](int j, bool gated) -> int32_t {
+            const int slot = j % kSlots, o = j * launch_q, m = std::min(launch_q, nq - o);
+            HR_CHECK_HIP(hipStreamWaitEvent(pipe_tail, pipe_scanned[slot], 0));
+            if (gated && gate && ws[slot].seq != 0)
+                HR_CHECK_HIP(hipStreamWaitValue64(pipe_tail, gate, ws[slot].seq + 1, hipStreamWaitValueGte, ~0ull));
+            const int32_t frc = finish_dev(q_dev + (int64_t)o * d, m, k, slot, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
+                                           oidp + (int64_t)o * k, pipe_tail);
+            if (frc) return frc;
+            HR_CHECK_HIP(hipEventRecord(pipe_done[slot], pipe_tail));
+            return HIPRAG_OK;
+        };
+        rc = HIPRAG_OK;
+        int launched = 0;
+        for (int j = 0; j < L && !rc; ++j) {
+            const int slot = j % kSlots, o = j * launch_q, m = std::min(launch_q, nq - o);
+            if (j >= kSlots) rc = hipStreamWaitEvent(hp, pipe_done[slot], 0) == hipSuccess ? HIPRAG_OK : HIPRAG_E_HIP;   // the slot's previous finish
+            if (!rc) rc = prepare(k, slot);
+            if (!rc) rc = begin_dev(q_dev + (int64_t)o * d, m, k, slot, hp);
+            if (!rc) rc = hipEventRecord(pipe_scanned[slot], hp) == hipSuccess ? HIPRAG_OK : HIPRAG_E_HIP;
+            if (!rc) { launched = j + 1; if (j >= 1) rc = tails(j - 1, true); }
+        }
+        scan_cus = saved_cus;
+        // the last launched scan's finish has no scan behind it: no gate (nothing would open it)
+        if (launched > 0) { const int32_t trc = tails(launched - 1, false); if (!rc) rc = trc; }
+        if (launched > 0) HR_CHECK_HIP(hipStreamWaitEvent(st, pipe_done[(launched - 1) % kSlots], 0));   // the tail stream is in order: the last finish is behind all others
+        if (rc == HIPRAG_E_HIP) set_error("a HIP call failed while enqueueing a pipelined search: %s", hipGetErrorString(hipGetLastError()));
+        return rc;
+    }
+
     int32_t search_dev(const float* q_dev, int nq, int k, double* o64p, float* o32p, int64_t* oidp, hipStream_t st)
     {
         int32_t rc = prepare(k, 0);
         if (rc) return rc;
+        if (nq > launch_q && nblocks() > 0 && fast_k(k)) return search_dev_pipelined(q_dev, nq, k, o64p, o32p, oidp, st);
         for (int o = 0; o < nq; o += launch_q) {
             const int m = std::min(launch_q, nq - o);
             const float* qo = q_dev + (int64_t)o * d;

@@ -469,6 +469,36 @@ def test_deep_pipeline_with_changing_batch_shapes(gpu, tails, monkeypatch):
         assert np.allclose(s32.cpu().numpy(), es, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("metric", [ho.METRIC_IP, ho.METRIC_L2])
+def test_batches_of_several_launches_are_pipelined_inside_the_library(gpu, monkeypatch, metric):
+    """hipidx_search / hipidx_search_dev with more queries than one launch takes: the library chains the scans on its scan
+    stream and runs every finish but the last beside the next scan (start gate), results ordered on the caller's stream.
+    Launch size forced down to 64 queries so that 300 queries are five launches and 700 eleven (more than the eight
+    workspace slots: slots are reused inside one call); a caller's own stream; k = 10 and 50; ids equal the oracle's and the
+    call leaves the index's spare-CU setting alone."""
+    import torch
+    from hiprag import HipFlatIndex
+    monkeypatch.setenv("HIPRAG_LAUNCH_QUERIES", "64")
+    n, d = 30011, 256
+    x = ho.synthetic_vectors(n, d, seed=95)
+    q = ho.synthetic_queries(700, d, seed=96)
+    ix = HipFlatIndex(d, metric)
+    ix.add(x)
+    assert ix.launch_queries == 64
+    ix.set_spare_cus(5)
+    for nq, k in ((300, 10), (700, 50), (65, 1)):
+        _check(ix, x, q[:nq], k, metric)                                   # host arrays in and out (null stream)
+        _, ei = ho.flat_search(x, q[:nq], k, metric)
+        mine = torch.cuda.Stream()
+        with torch.cuda.stream(mine):
+            qd = torch.from_numpy(q[:nq]).cuda() * 1.0                     # produced on the caller's stream right before
+            out = ix.search_device(qd, k)
+            back = out[2].cpu()                                            # consumed on it right after
+        mine.synchronize()
+        assert np.array_equal(back.numpy(), ei), (nq, k)
+    assert ix.spare_cus == 5
+
+
 def test_start_gate_orders_a_finish_behind_the_start_of_the_next_scan(gpu):
     """hipidx_gate_tail_dev by hand, the way a C host would use it: scans chained on the library's scan stream, the finish of
     step i on a tail stream behind (a) the end of scan i and (b) the START of scan i + 1.  The library refuses a gate that
