@@ -764,6 +764,18 @@ def main():
         lat_dev.append((time.perf_counter() - t1) * 1e3)
     lat = np.sort(np.asarray(lat[20:]))
     lat_dev = np.sort(np.asarray(lat_dev[20:]))
+    # the same index through ONE library call per batch of all N_QUERIES queries (hipidx_search_dev pipelines the launches of
+    # such a batch itself: no Python between the steps, no timing events) -- the local shard only, no exchange
+    one_call_qps = None
+    if world == 1:
+        for _ in range(2):
+            index.search_device(queries, TOPK)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(6):
+            index.search_device(queries, TOPK)
+        torch.cuda.synchronize()
+        one_call_qps = round(6 * N_QUERIES / (time.perf_counter() - t1), 1)
 
     rows_local = [int(index.ntotal)]
     per_rank = [{"rank": 0, "rows": int(index.ntotal), "scan_ms": round(scan_ms, 5), "scan_ms_gpu_clock": round(wall_ms, 5),
@@ -819,6 +831,7 @@ def main():
         "p99_ms_single_query": round(float(lat[int(len(lat) * 0.99) - 1]), 4),
         "p50_ms_single_query_device_resident": round(float(lat_dev[len(lat_dev) // 2]), 4),
         "latency_path": "hipidx_search: host query in, host results out (H2D + scan + tails + D2H + sync) on the local shard",
+        "one_hipidx_search_dev_call_per_4096_queries_qps": one_call_qps,
         "fallback_queries": sum(r["fallback_queries"] for r in per_rank),
         "finish_work_rank0": {"extended_queries_share": round(st["roundb_queries"] / max(1, st["queries"]), 4),
                               "list_entries_per_query": round(st["list_entries"] / max(1, st["queries"]), 1),
