@@ -138,16 +138,18 @@ int32_t hipidx_search_finish_dev(uint64_t h, const float* q_dev, int32_t nq, int
  * calls and the row-sharded hosts set it themselves (hiphybrid_search*: 96 for the dense leg of the call). */
 int32_t hipidx_set_spare_cus(uint64_t h, int32_t n);
 int32_t hipidx_get_spare_cus(uint64_t h, int32_t* out_n);
-/* The START GATE: make `stream` (a tail stream) wait -- in the command processor, no CU is held -- until the scan launched
- * AFTER the one of `slot` has STARTED, i.e. until every workgroup of that next scan holds its CU.  Enqueued on the tail
- * stream between the wait for the slot's own scan and hipidx_search_finish_dev, it makes the finish (and whatever follows:
- * an all-gather, a merge) be dispatched onto the CUs the next scan has left (hipidx_set_spare_cus), beside it, instead of
- * racing it for CUs: which of two queues that become ready at the same moment is served first is not something a host can
- * steer (measured: 0.89-1.23 M queries/s on a 125 k-row shard for one and the same arrangement of streams, depending only on
- * which hardware queues the streams happened to get; with the gate 1.22-1.23 M whatever they got).  The next scan must have
- * been LAUNCHED already (error otherwise: nothing else ever opens the gate) -- so a pipelined host enqueues the tails of
- * step i right after it has launched the scan of step i + 1, and without the gate when it needs step i's result before
- * another scan is due (hiprag/sharded.py).  A no-op where hipStreamWaitValue64 / signal memory are not available. */
+/* The START GATE: make `stream` (a tail stream) wait until the scan launched AFTER the one of `slot` has STARTED, i.e. until
+ * every workgroup of that next scan holds its CU (the scan counts its workgroups in and raises a word; a one-wave kernel on
+ * `stream` polls it).  Enqueued on the tail stream between the wait for the slot's own scan and hipidx_search_finish_dev, it
+ * makes the finish (and whatever follows: an all-gather, a merge) be dispatched onto the CUs the next scan has left
+ * (hipidx_set_spare_cus), beside it, instead of racing it for CUs: which of two queues that become ready at the same moment
+ * is served first is not something a host can steer (measured: 0.89-1.23 M queries/s on a 125 k-row shard for one and the
+ * same arrangement of streams, depending only on which hardware queues the streams happened to get).  The next scan must
+ * have been LAUNCHED already (error otherwise) -- so a pipelined host enqueues the tails of step i right after it has launched
+ * the scan of step i + 1, and without the gate when it needs step i's result before another scan is due (hiprag/sharded.py;
+ * hipidx_search_dev does the same for a batch of several launches).  The wait is BOUNDED (1 ms: the gate opens ~30 us after
+ * the previous scan has ended): where kernels are serialised -- counter collection, a debugger -- the awaited scan cannot
+ * start while the wait runs, and the gate then simply times out. */
 int32_t hipidx_gate_tail_dev(uint64_t h, int32_t slot, void* stream);
 /* make sure slot 0's search workspace for k exists so that search / search_dev never allocate */
 int32_t hipidx_reserve_search(uint64_t h, int32_t k);

@@ -238,7 +238,7 @@ struct ScanArgs {
     // the tail streams of the PREVIOUS launch wait on
     unsigned long long* started;
     unsigned long long target, seq;
-    unsigned long long* gate;     // signal memory, or null
+    unsigned long long* gate;     // the gate word (device memory)
 };
 
 __host__ __device__ __forceinline__ int64_t scan_blocks_per_wave(int64_t nblocks, int64_t nwaves)
@@ -707,7 +707,7 @@ __device__ __forceinline__ void stage_query_tile_image(const bf16x8* __restrict_
     if (a.stamps && lane == 0) a.stamps[2 * gw] = wall_clock64();                                                        \
     if (a.gate && tid == 0) {                                                                                            \
         const unsigned long long was = __hip_atomic_fetch_add(a.started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-        if (was + 1 == a.target) __hip_atomic_fetch_max(a.gate, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      \
+        if (was + 1 == a.target) __hip_atomic_fetch_max(a.gate, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       \
     }                                                                                                                    \
     TailLds L;                                                                                                           \
     L.stage = reinterpret_cast<Cand*>(reinterpret_cast<char*>(qs) + (size_t)a.P * 1024);                                 \
@@ -1405,6 +1405,24 @@ static int32_t ensure_lds(const void* fn, size_t bytes)
     return HIPRAG_OK;
 }
 
+// The start gate's wait (hipidx_gate_tail_dev): one wave polls the gate word -- memory-side reads, a plain load could be
+// served from a stale L2 line for ever -- until the awaited scan has raised it, or until the bound is up.  The bound is
+// what makes the gate safe where kernels are serialised (a profiler collecting counters, AMD_SERIALIZE_KERNEL, a debugger):
+// there the awaited scan cannot start while this kernel runs, and an unbounded wait (hipStreamWaitValue64, which this
+// replaces: it hung a --pmc collection) would never end.  The gate opens ~30 us after the previous scan has ended -- which
+// the stream has waited for before it gets here -- so 1 ms of the 100 MHz wall clock is far beyond any real wait; a gate that
+// times out only costs the overlap it was there for.
+constexpr unsigned long long kGateTimeoutTicks = 100000ull;
+__global__ __launch_bounds__(64) void gate_wait_kernel(unsigned long long* gate, unsigned long long target)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_fetch_or(gate, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (wall_clock64() - t0 > kGateTimeoutTicks) break;
+        __builtin_amdgcn_s_sleep(20);
+    }
+}
+
 struct DenseIndex {
     std::mutex mu;
     int device = 0;
@@ -1432,8 +1450,8 @@ struct DenseIndex {
     // pinned host staging of hipidx_search's few-query path (device-visible under the same address): the query goes up with
     // an asynchronous copy, the finish writes scores, ids and flags straight into host memory
     PinBuf pin_q, pin_o32, pin_oid, pin_flags;
-    // start gate: see ScanArgs.  `gate` is signal memory (hipMallocSignalMemory: what hipStreamWaitValue64 may wait on),
-    // `started` a device counter; both only ever grow.
+    // start gate: see ScanArgs.  `started` holds the workgroup counter and, on a line of its own, the gate word; both only
+    // ever grow.
     unsigned long long* gate = nullptr;
     DevBuf started;
     unsigned long long scan_seq = 0, started_total = 0;
@@ -1479,7 +1497,6 @@ struct DenseIndex {
 
     ~DenseIndex()
     {
-        if (gate) (void)hipFree(gate);
         if (pipe_tail) (void)hipStreamDestroy(pipe_tail);
         if (pipe_in) (void)hipEventDestroy(pipe_in);
         for (int i = 0; i < kSlots; ++i) {
@@ -1507,17 +1524,9 @@ struct DenseIndex {
         update_launch_q();
         int32_t rc = scalars.reserve(64);
         if (rc) return rc;
-        if ((rc = started.reserve(64))) return rc;
-        HR_CHECK_HIP(hipMemset(started.p, 0, 64));
-        {
-            void* g = nullptr;
-            if (hipExtMallocWithFlags(&g, 8, hipMallocSignalMemory) == hipSuccess && g) {
-                gate = reinterpret_cast<unsigned long long*>(g);
-                HR_CHECK_HIP(hipMemset(g, 0, 8));
-            } else {
-                (void)hipGetLastError();   // no signal memory: tails are not gated (hipidx_gate_tail_dev does nothing)
-            }
-        }
+        if ((rc = started.reserve(256))) return rc;
+        HR_CHECK_HIP(hipMemset(started.p, 0, 256));
+        gate = started.as<unsigned long long>() + 16;   // its own 128-byte line
         HR_CHECK_HIP(hipMemset(scalars.p, 0, 64));
         HR_CHECK_HIP(hipStreamSynchronize(nullptr));   // hipMemset of device memory may return before the fill has run
         return HIPRAG_OK;
@@ -1896,8 +1905,8 @@ struct DenseIndex {
         auto tails = [&](int j, bool gated) -> int32_t {
             const int slot = j % kSlots, o = j * launch_q, m = std::min(launch_q, nq - o);
             HR_CHECK_HIP(hipStreamWaitEvent(pipe_tail, pipe_scanned[slot], 0));
-            if (gated && gate && ws[slot].seq != 0)
-                HR_CHECK_HIP(hipStreamWaitValue64(pipe_tail, gate, ws[slot].seq + 1, hipStreamWaitValueGte, ~0ull));
+            if (gated && ws[slot].seq != 0)
+                hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, pipe_tail, gate, ws[slot].seq + 1);
             const int32_t frc = finish_dev(q_dev + (int64_t)o * d, m, k, slot, o64p + (int64_t)o * k, o32p ? o32p + (int64_t)o * k : nullptr,
                                            oidp + (int64_t)o * k, pipe_tail);
             if (frc) return frc;
@@ -2157,9 +2166,11 @@ int32_t hipidx_gate_tail_dev(uint64_t h, int32_t slot, void* stream)
     HR_REQUIRE(slot >= 0 && slot < DenseIndex::kSlots, "slot must be in 0..7");
     const unsigned long long seq = ix->ws[slot].seq;
     if (!ix->gate || seq == 0) return HIPRAG_OK;
-    // only a scan that is already on its way can open the gate: a wait for one that may never be launched would hang the stream
+    // only a scan that is already on its way can open the gate: a wait for one that has not been launched is a mistake of the
+    // caller's (it would merely run into the wait's time limit)
     HR_REQUIRE(ix->scan_seq > seq, "hipidx_gate_tail_dev: no scan has been launched after the one of slot %d", slot);
-    HR_CHECK_HIP(hipStreamWaitValue64((hipStream_t)stream, ix->gate, seq + 1, hipStreamWaitValueGte, ~0ull));
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ix->gate, seq + 1);
+    HR_CHECK_HIP(hipGetLastError());
     return HIPRAG_OK;
 }
 

@@ -6,10 +6,11 @@ R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0
 from hiprag import HipFlatIndex
 N=int(os.environ.get('ROWS','1000000')); d=1024; k=10
 g=torch.Generator(device='cuda'); g.manual_seed(1234)
-ix=HipFlatIndex(d,'ip'); B=ix.launch_queries
+ix=HipFlatIndex(d,'ip')
 for lo in range(0,N,125000):
     m=min(125000,N-lo)
     x=torch.randn((m,d),generator=g,device='cuda',dtype=torch.float32); x/=x.norm(dim=1,keepdim=True); ix.add_device(x)
+B=ix.launch_queries   # AFTER the rows are in: exactly one launch per call (a larger batch would be pipelined by the library)
 q=torch.randn((B,d),generator=g,device='cuda'); q/=q.norm(dim=1,keepdim=True)
 out=None
 for _ in range(5): out=ix.search_device(q,k,out)
