@@ -48,6 +48,12 @@ int32_t hiprag_device_sync(int32_t device);
  * previous launch, a BM25 leg, an all-gather -- do not take the scan's CUs first: a scan workgroup needs an empty CU, the
  * others are many small workgroups, and the dispatcher serves the high-priority queue first (hipidx_set_spare_cus). */
 int32_t hiprag_scan_stream(int32_t device, void** out_stream);
+/* The device's two TAIL STREAMS (which = 0 / 1; normal priority, owned by the library): where the kernels that run beside a
+ * scan belong -- the finish of the previous launch, an exchange, a merge.  One pair per device for the whole process: HIP
+ * hands its four hardware queues per priority to streams in order of first use and lets later streams share them, and a
+ * process that creates tail streams per index or per wrapper object slows its later pipelines down by that alone.  The
+ * library's own pipeline (hipidx_search_dev) uses which = 0. */
+int32_t hiprag_tail_stream(int32_t device, int32_t which, void** out_stream);
 /* Optional process-level bracket: init checks that n_devices GPUs are visible (<= 0: at least one) and
  * creates their contexts up front; shutdown synchronises every device and drops every handle still registered (their
  * device memory goes with them) -- the reference has no counterpart, its indices live until the process exits

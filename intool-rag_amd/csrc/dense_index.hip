@@ -1497,7 +1497,6 @@ struct DenseIndex {
 
     ~DenseIndex()
     {
-        if (pipe_tail) (void)hipStreamDestroy(pipe_tail);
         if (pipe_in) (void)hipEventDestroy(pipe_in);
         for (int i = 0; i < kSlots; ++i) {
             if (pipe_scanned[i]) (void)hipEventDestroy(pipe_scanned[i]);
@@ -1875,7 +1874,12 @@ struct DenseIndex {
     int32_t pipe_init()
     {
         if (pipe_tail) return HIPRAG_OK;
-        HR_CHECK_HIP(hipStreamCreateWithFlags(&pipe_tail, hipStreamNonBlocking));
+        {   // the device's tail stream 0 (library-owned, shared by every index of the device: lib.cpp)
+            void* t = nullptr;
+            const int32_t trc = hiprag_tail_stream(device, 0, &t);
+            if (trc) return trc;
+            pipe_tail = (hipStream_t)t;
+        }
         HR_CHECK_HIP(hipEventCreateWithFlags(&pipe_in, hipEventDisableTiming));
         for (int i = 0; i < kSlots; ++i) {
             HR_CHECK_HIP(hipEventCreateWithFlags(&pipe_scanned[i], hipEventDisableTiming));

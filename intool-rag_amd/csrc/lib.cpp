@@ -52,17 +52,44 @@ public:
         out = it->second;
         return HIPRAG_OK;
     }
+    // The device's TAIL STREAMS (two, normal priority): where the kernels that run beside a scan are enqueued -- the finish
+    // of the previous launch, an exchange, a merge.  One pair per device for the whole process, not one per index or per
+    // wrapper object: HIP has four hardware queues per priority and hands them out in order of first use, streams beyond
+    // that SHARE queues, and a process that multiplied its tail streams (one pair per ShardedFlatIndex, a stream per index
+    // for the library's own pipeline) slowed its later pipelines down by that alone.
+    int32_t get_tail(int dev, int which, hipStream_t& out)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        const long long key = (long long)dev * 2 + (which & 1);
+        auto it = tail_.find(key);
+        if (it == tail_.end()) {
+            int cur = 0;
+            hipStream_t st = nullptr;
+            HR_CHECK_HIP(hipGetDevice(&cur));
+            HR_CHECK_HIP(hipSetDevice(dev));
+            const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            (void)hipSetDevice(cur);
+            HR_CHECK_HIP(e);
+            it = tail_.emplace(key, st).first;
+        }
+        out = it->second;
+        return HIPRAG_OK;
+    }
     void clear()   // hiprag_shutdown, every device synchronised
     {
         std::lock_guard<std::mutex> g(mu_);
         for (auto& kv : hp_)
             if (hipSetDevice(kv.first) == hipSuccess) (void)hipStreamDestroy(kv.second);
         hp_.clear();
+        for (auto& kv : tail_)
+            if (hipSetDevice((int)(kv.first / 2)) == hipSuccess) (void)hipStreamDestroy(kv.second);
+        tail_.clear();
     }
 
 private:
     std::mutex mu_;
     std::unordered_map<int, hipStream_t> hp_;
+    std::unordered_map<long long, hipStream_t> tail_;
 };
 static ScanStreams& scan_streams()
 {
@@ -414,6 +441,16 @@ int32_t hiprag_scan_stream(int32_t device, void** out_stream)
     HR_REQUIRE(out_stream, "null out");
     hipStream_t st = nullptr;
     int32_t rc = scan_streams().get(device, st);
+    if (rc) return rc;
+    *out_stream = (void*)st;
+    return HIPRAG_OK;
+}
+
+int32_t hiprag_tail_stream(int32_t device, int32_t which, void** out_stream)
+{
+    HR_REQUIRE(out_stream && (which == 0 || which == 1), "which must be 0 or 1");
+    hipStream_t st = nullptr;
+    int32_t rc = scan_streams().get_tail(device, which, st);
     if (rc) return rc;
     *out_stream = (void*)st;
     return HIPRAG_OK;

@@ -18,4 +18,5 @@ def shutdown() -> None:
     handle must not be used afterwards (their close() then reports an unknown handle)."""
     _native.call("hiprag_shutdown")
     from . import sharded
-    sharded._SCAN_STREAMS.clear()      # wrappers of the library's scan streams, destroyed with it
+    sharded._SCAN_STREAMS.clear()      # wrappers of the library's scan and tail streams, destroyed with it
+    sharded._TAIL_STREAMS.clear()

@@ -42,6 +42,7 @@ SIGNATURES = {
     "hiprag_device_count": [i32p],
     "hiprag_device_sync": [c_int32],
     "hiprag_scan_stream": [c_int32, c_void_p],
+    "hiprag_tail_stream": [c_int32, c_int32, c_void_p],
     "hiprag_init": [c_int32],
     "hiprag_shutdown": [],
     "hiphybrid_search": [c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float,

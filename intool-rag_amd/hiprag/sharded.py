@@ -85,18 +85,30 @@ def all_gather_packed(pack, gathered, group=None, async_op: bool = True):
 
 
 def _slot_streams(device):
-    """The streams the tails of the N_SLOTS workspace slots run on: HIPRAG_SIDE_STREAMS of them (default 2), the slots
-    taking turns.  HIP maps streams onto four hardware queues and streams that share a queue execute in submission order:
-    with one stream per slot a third of the slots shared the queue of the caller's stream (or of RCCL's), and every such
-    step ran its tail -- and the all-gather behind it -- BEFORE the next scan instead of beside it.  Caller's stream + two
-    tail streams + RCCL's stream = four queues, nothing shared; more hardware queues (GPU_MAX_HW_QUEUES = 8 / 16, or
-    high-priority tail streams, which come from a second queue pool) are time-sliced and lengthen the gap between launches
-    two- to fivefold instead.  Measured on a 125 k-row shard with the exchange on (one-rank RCCL group): 1.04 M queries/s
-    with eight tail streams, 1.14-1.19 M with two."""
+    """The streams the tails of the N_SLOTS workspace slots run on: the device's two tail streams (hiprag_tail_stream, owned by
+    the library, ONE pair per device and process), the slots taking turns -- HIPRAG_SIDE_STREAMS=1 puts every slot on the
+    first.  Two, so that the tail of batch i never queues behind that of batch i + 1 around an exchange.  One pair per
+    PROCESS because HIP maps streams onto four hardware queues per priority in order of first use and lets later streams
+    share queues: with a pair per ShardedFlatIndex object a process that built several of them (bench.py's legs) ran the later
+    ones with shared queues, and streams that share a queue execute in submission order.  More hardware queues
+    (GPU_MAX_HW_QUEUES = 8 / 16) or high-priority tail streams (a second queue pool) are time-sliced and lengthen the gap
+    between launches two- to fivefold instead."""
+    import ctypes
     import torch
-    n = max(1, min(N_SLOTS, int(os.environ.get("HIPRAG_SIDE_STREAMS", "2"))))
-    pool = [torch.cuda.Stream(device=device) for _ in range(n)]
+    from . import _native as nat
+    n = max(1, min(2, int(os.environ.get("HIPRAG_SIDE_STREAMS", "2"))))
+    pool = []
+    for which in range(n):
+        st = _TAIL_STREAMS.get((device, which))
+        if st is None:
+            ptr = ctypes.c_void_p()
+            nat.call("hiprag_tail_stream", int(device), which, ctypes.byref(ptr))
+            st = _TAIL_STREAMS[(device, which)] = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", int(device)))
+        pool.append(st)
     return [pool[i % n] for i in range(N_SLOTS)]
+
+
+_TAIL_STREAMS = {}
 
 
 def _exchange_on(world: int) -> bool:
