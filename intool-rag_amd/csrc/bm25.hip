@@ -544,7 +544,11 @@ struct Bm25Index {
         int32_t rc;
         int longest = 0;
         for (int b = 0; b < nq; ++b) longest = std::max(longest, qoff[b + 1] - qoff[b]);
-        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * kTileWaves * k <= 64 * 64 * 16)
+        // the tiled form for any collection whose per-query candidate lists (4 per tile x k) stay below a million entries --
+        // 20 M documents at k = 50; the merge walks lists of any length (merge_packed_loop_kernel).  (Until late round 3 the
+        // limit was 65536 entries = 3 M documents at k = 50: a 10M-document shard on one GPU fell back to the
+        // global-accumulator form, 200 ms per 256 queries.)
+        if (!force_global && k <= 64 && longest <= kMaxSlots && ntiles() * kTileWaves * k <= (i64)1 << 20)
             return search_tiled(terms, qoff, nq, k, o64p, o32p, oidp, st);
         if ((rc = reserve(k))) return rc;
         for (int q0 = 0; q0 < nq; q0 += kBatch) {

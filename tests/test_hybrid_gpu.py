@@ -534,6 +534,29 @@ def test_bm25_tiled_and_global_accumulator_forms_agree_with_the_oracle(gpu, monk
         HipBM25(PostingsCSR(p.n_docs, p.n_terms, p.offsets, bad, p.impacts))
 
 
+def test_bm25_tiled_form_beyond_three_million_documents(gpu):
+    """4.2 M documents at depth 50 = 456 tiles x 4 lists x 50 = 91 k candidate slots per query, past the 65536 the tiled form
+    used to stop at (a 10M-document shard on one GPU then took the global-accumulator form: 200 ms per 256 queries): the
+    lists of every length go through merge_packed_loop_kernel.  Short documents (three tokens each, 1000 terms) keep the
+    oracle cheap; ids and fp32 scores bit-exact, also for a query of one frequent term and one of an unknown term."""
+    from hiprag import HipBM25
+    n_docs, n_terms, depth = 4_200_000, 1000, 50
+    rng = np.random.default_rng(61)
+    doc = np.repeat(np.arange(n_docs, dtype=np.int64), 3)
+    w = 1.0 / np.arange(1, n_terms + 1)
+    cdf = np.cumsum(w) / w.sum()
+    term = np.minimum(np.searchsorted(cdf, rng.random(doc.size)), n_terms - 1)
+    p = ho.build_postings_from_pairs(doc, term, n_docs, n_terms)
+    bm = HipBM25(_gpu_postings(p))
+    sq = [rng.choice(np.arange(20, n_terms), size=5, replace=False).astype(np.uint32) for _ in range(10)]
+    sq += [np.asarray([0], dtype=np.uint32), np.asarray([3, 5000], dtype=np.uint32)]
+    es, ei = ho.bm25_search(p, sq, depth)
+    gs, gi = bm.search(sq, depth)
+    assert np.array_equal(gi, ei) and np.array_equal(gs, es)
+    st = bm.stats()
+    assert st["queries"] >= len(sq)
+
+
 def test_hybrid_search_device_overlaps_the_legs_and_equals_the_oracle(gpu):
     """hiphybrid_search_dev (hiprag.hybrid_search_device: the dense leg on the library's high-priority scan stream with
     CUs left out of its grid, BM25 beside it on the caller's stream, the fusion behind both) and the host-array call
