@@ -1093,12 +1093,14 @@ struct FinArgs {
     int d, P, k, mode, filter;
 };
 
-template <int METRIC>
-// (kFinThreads, 4): four waves per SIMD, i.e. TWO of these 8-wave workgroups per CU.  Left alone the compiler takes 142
+// NT threads: 512 (8 waves) for shallow k, 1024 (16 waves) for k >= 32, where re-scoring k + k/2 groups one after the other
+// in 8 waves is most of a finish workgroup's time (k = 50: 229 us per 256-query launch with 8 waves).
+template <int METRIC, int NT>
+// (NT, 4): four waves per SIMD, i.e. TWO of these 8-wave workgroups per CU.  Left alone the compiler takes 142
 // VGPRs -- three waves per SIMD, ONE workgroup per CU -- and a finish workgroup is a ~0.15 ms chain of dependent steps
 // that only other workgroups on the CU can hide: on the CUs the next scan leaves it the finish of 1024
 // queries then lasted as long as the scan itself.  128 VGPRs cost 36 bytes of scratch per lane.
-__global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
+__global__ __launch_bounds__(NT, 4) void fin_kernel(FinArgs a)
 {
     __shared__ float qv[kMaxDPad];
     // the unsorted list (lkey / lsec) is dead once it has been ranked into skey / ssec: the re-scored rows (ck / ci) overlay it
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
 
     // query into LDS (zero padded), its exact |q|^2 and |q - bf16(q)|^2 (the scan's query tile holds bf16(q), RNE)
     double qpart = 0.0, dpart = 0.0;
-    for (int c = tid; c < dpad; c += kFinThreads) {
+    for (int c = tid; c < dpad; c += NT) {
         const float vf = c < a.d ? a.q[(int64_t)q * a.d + c] : 0.f;
         qv[c] = vf;
         const double v = (double)vf, dv = v - (double)(float)(__bf16)vf;
@@ -1132,21 +1134,21 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { qpart += __shfl_xor(qpart, off); dpart += __shfl_xor(dpart, off); }
-    if (lane == 0) { dred[wave] = qpart; dred[16 + wave] = dpart; }   // kFinThreads / 64 <= 16 waves
+    if (lane == 0) { dred[wave] = qpart; dred[16 + wave] = dpart; }   // NT / 64 <= 16 waves
     if (tid == 0) { s_n = 0; s_r1 = 0; s_expand = 0; }
     if (tid < k) { tk[tid] = 0; ti[tid] = -1; }
     const u32 cnt_raw = a.count[q];
     const u32 theta = a.filter ? a.thetac[q] : 0u;
     __syncthreads();
     double qn2 = 0.0, dq2 = 0.0;
-    for (int w = 0; w < kFinThreads / 64; ++w) { qn2 += dred[w]; dq2 += dred[16 + w]; }
+    for (int w = 0; w < NT / 64; ++w) { qn2 += dred[w]; dq2 += dred[16 + w]; }
     const double eps = scan_eps<METRIC>(dpad, a.mode, qn2, (double)__uint_as_float(a.max_norm2_bits[0]), dq2,
                                         (double)__uint_as_float(a.max_norm2_bits[1]));
 
     // 1. list -> LDS
     const int n_in = (int)min(cnt_raw, (u32)kCandCap);
     const Cand* src = a.list + (size_t)q * kCandCap;
-    for (int i = tid; i < n_in; i += kFinThreads) {
+    for (int i = tid; i < n_in; i += NT) {
         const Cand e = src[i];
         if ((u32)(e.key >> 32) >= theta) {
             const int p = atomicAdd(&s_n, 1);
@@ -1165,7 +1167,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
 
     // rows of groups [g0, g1) of the sorted list -> ck / ci[4j ..]
     auto rescore_groups = [&](int g0, int g1) {
-        for (int j = g0 + wave; j < g1; j += kFinThreads / 64) {
+        for (int j = g0 + wave; j < g1; j += NT / 64) {
             const u64 e = skey[j];
             const u32 gid = packed_index(e);
             const int g = (int)(__float_as_uint(packed_value(e)) & 3u);
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
         __syncthreads();
         if (tid < k) { tk[tid] = 0; ti[tid] = -1; }
         __syncthreads();
-        for (int i = tid; i < nc; i += kFinThreads) {
+        for (int i = tid; i < nc; i += NT) {
             const u64 mk = ck[i];
             if (mk == 0) continue;
             const i64 mi = ci[i];
@@ -1201,7 +1203,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
 
     if (!flag) {
         // 2. rank by counting
-        for (int i = tid; i < n; i += kFinThreads) {
+        for (int i = tid; i < n; i += NT) {
             const u64 mine = lkey[i];
             int r = 0;
             for (int j = 0; j < n; ++j) r += lkey[j] > mine ? 1 : 0;
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
             const double t = kth_on_scan_scale<METRIC>(kth_key, qn2) - eps;
             float tf = t > -3.0e38 ? (float)t : -FLT_MAX;
             if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
-            for (int j = R0 + tid; j < n; j += kFinThreads)
+            for (int j = R0 + tid; j < n; j += NT)
                 if (packed_value(skey[j]) >= tf) atomicMax(&s_r1, j + 1);
             __syncthreads();
             const int R1 = s_r1;
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
     if (!flag) {
         // 5. other quads of groups whose `second` could still reach the k-th score
         const double kth = kth_on_scan_scale<METRIC>(kth_key, qn2);
-        for (int j = tid; j < R; j += kFinThreads) {
+        for (int j = tid; j < R; j += NT) {
             const float m2 = ssec[j];
             if (m2 > -1.0e38f && !(kth > (double)m2 + eps)) {
                 const int p = atomicAdd(&s_expand, 1);
@@ -1248,7 +1250,7 @@ __global__ __launch_bounds__(kFinThreads, 4) void fin_kernel(FinArgs a)
         const int ne = s_expand;
         if (ne > kMaxExpand) flag = true;
         else if (ne > 0) {
-            for (int x = wave; x < ne; x += kFinThreads / 64) {
+            for (int x = wave; x < ne; x += NT / 64) {
                 const u64 e = skey[expand[x]];
                 const u32 gid = packed_index(e);
                 const int tagged = (int)(__float_as_uint(packed_value(e)) & 3u);
@@ -1760,7 +1762,8 @@ struct DenseIndex {
             fa.list = w.list.as<Cand>();
             fa.ntotal = ntotal; fa.id_base = id_base; fa.d = d; fa.P = P; fa.k = k; fa.mode = scan_mode;
             fa.filter = 2 * nb > kNoFilterGroups ? 1 : 0;
-            hipLaunchKernelGGL(fin_kernel<METRIC>, dim3(nq), dim3(kFinThreads), 0, st, fa);
+            if (k >= 32) hipLaunchKernelGGL((fin_kernel<METRIC, 1024>), dim3(nq), dim3(1024), 0, st, fa);
+            else hipLaunchKernelGGL((fin_kernel<METRIC, kFinThreads>), dim3(nq), dim3(kFinThreads), 0, st, fa);
             w.dirty = false;
         } else {
             hipLaunchKernelGGL(flag_all_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, flags, arrivals, fallback_counter(), nq);
